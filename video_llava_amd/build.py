@@ -1,0 +1,75 @@
+"""Build libpgv.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+`hipcc --offload-arch=gfx950` cross-compiles without a GPU, so this runs in the build container
+as well as on the GPU box.  Objects are cached under video_llava_amd/_build keyed by source mtime.
+"""
+from __future__ import annotations
+
+import concurrent.futures
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "_build")
+LIB = os.path.join(HERE, "libpgv.so")
+SOURCES = ["api.hip", "gemm.hip", "elementwise.hip", "vit_attn.hip", "weights.hip", "vit.hip", "llm_kernels.hip", "llm.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+         "-ffp-contract=fast"]
+
+
+def _hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: libpgv needs the ROCm toolchain (no CPU fallback exists)")
+
+
+def _newest_header() -> float:
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs.append(os.path.join(os.path.dirname(HERE), "include", "pgv.h"))
+    return max(os.path.getmtime(h) for h in hs)
+
+
+def _compile(src: str, force: bool, verbose: bool) -> tuple[str, bool]:
+    spath = os.path.join(CSRC, src)
+    opath = os.path.join(OBJ, src.replace(".hip", ".o"))
+    stamp = max(os.path.getmtime(spath), _newest_header())
+    if not force and os.path.exists(opath) and os.path.getmtime(opath) >= stamp:
+        return opath, False
+    cmd = [_hipcc(), *FLAGS, "-c", spath, "-o", opath]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    if verbose and r.stderr.strip():
+        print(r.stderr, file=sys.stderr)
+    return opath, True
+
+
+def sources_present() -> list[str]:
+    return [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP translation unit and link libpgv.so; returns the library path."""
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = sources_present()
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        results = list(ex.map(lambda s: _compile(s, force, verbose), srcs))
+    objs = [o for o, _ in results]
+    if force or any(changed for _, changed in results) or not os.path.exists(LIB):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

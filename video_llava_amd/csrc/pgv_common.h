@@ -1,0 +1,154 @@
+// Internal helpers shared by the libpgv translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+
+#include "../../include/pgv.h"
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------
+void pgv_set_error(const char* fmt, ...);
+
+#define PGV_HIP(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            pgv_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return PGV_EHIP;                                                                   \
+        }                                                                                      \
+    } while (0)
+
+#define PGV_CHECK(cond, ...)                                                                   \
+    do {                                                                                       \
+        if (!(cond)) {                                                                         \
+            pgv_set_error(__VA_ARGS__);                                                        \
+            return PGV_EINVAL;                                                                 \
+        }                                                                                      \
+    } while (0)
+
+#define PGV_TRY(expr)                                                                          \
+    do {                                                                                       \
+        int _r = (expr);                                                                       \
+        if (_r != PGV_OK) return _r;                                                           \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// context: device + bump-allocated workspace arena + optional per-family event timers
+// ---------------------------------------------------------------------------------------------
+struct pgv_prof_family {
+    std::vector<hipEvent_t> ev;   // start/stop pairs
+    size_t used = 0;              // events used
+    double flops = 0, bytes = 0;
+    int64_t launches = 0;
+};
+
+struct pgv_ctx {
+    int device = 0;
+    int num_cu = 256;
+    char* ws = nullptr;
+    size_t ws_bytes = 0;
+    size_t ws_off = 0;
+    bool prof = false;
+    pgv_prof_family fam[PGV_NFAMILY];
+};
+
+// Reserve the arena for a call (may hipMalloc: never call inside graph capture).
+int pgv_ws_reserve(pgv_ctx* ctx, size_t bytes);
+// Bump allocate (256-B aligned) from the reserved arena; nullptr if exhausted.
+void* pgv_ws_alloc(pgv_ctx* ctx, size_t bytes);
+inline void pgv_ws_reset(pgv_ctx* ctx) { ctx->ws_off = 0; }
+inline size_t pgv_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+// RAII-free profiling scope helpers
+void pgv_prof_begin(pgv_ctx* ctx, int family, hipStream_t s);
+void pgv_prof_end(pgv_ctx* ctx, int family, hipStream_t s, double flops, double bytes);
+
+// ---------------------------------------------------------------------------------------------
+// device-side dtype traits
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) _Float16 half8_t;
+typedef __attribute__((ext_vector_type(4))) _Float16 half4_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 half2_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+
+struct TF16 {
+    using elem = _Float16;
+    using v8 = half8_t;
+    using v4 = half4_t;
+    using v2 = half2_t;
+    static constexpr int id = PGV_F16;
+    __device__ static inline f32x16_t mfma32(v8 a, v8 b, f32x16_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    __device__ static inline f32x4_t mfma16(v8 a, v8 b, f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+    __device__ static inline elem from_f32(float x) { return (_Float16)x; }
+    __device__ static inline float to_f32(elem x) { return (float)x; }
+};
+
+struct TBF16 {
+    using elem = __bf16;
+    using v8 = bf16x8_t;
+    using v4 = bf16x4_t;
+    using v2 = bf16x2_t;
+    static constexpr int id = PGV_BF16;
+    __device__ static inline f32x16_t mfma32(v8 a, v8 b, f32x16_t c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    __device__ static inline f32x4_t mfma16(v8 a, v8 b, f32x4_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+    __device__ static inline elem from_f32(float x) { return (__bf16)x; }
+    __device__ static inline float to_f32(elem x) { return (float)x; }
+};
+
+// pack 4 floats -> 4 x 16-bit (8 bytes)
+template <typename T>
+__device__ inline u32x2_t pack4(float a, float b, float c, float d) {
+    typename T::v4 v;
+    v[0] = T::from_f32(a); v[1] = T::from_f32(b); v[2] = T::from_f32(c); v[3] = T::from_f32(d);
+    return __builtin_bit_cast(u32x2_t, v);
+}
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// dispatch on runtime dtype
+#define PGV_DISPATCH_DTYPE(dtype, T, ...)                       \
+    do {                                                        \
+        if ((dtype) == PGV_F16) { using T = TF16; __VA_ARGS__; } \
+        else if ((dtype) == PGV_BF16) { using T = TBF16; __VA_ARGS__; } \
+        else { pgv_set_error("unsupported dtype %d", (int)(dtype)); return PGV_EINVAL; } \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// internal launchers (defined in the kernel translation units)
+// ---------------------------------------------------------------------------------------------
+struct GemmArgs {
+    const void* A; int lda;       // [M,K] 16-bit
+    const void* W; int ldw;       // [N,K] 16-bit (N padded to 256 rows, K to 64)
+    const float* bias;            // [N] fp32 or null
+    void* C; int ldc;             // 16-bit / fp32 out, or fp32 residual (RESID epilogues)
+    int M, N, K;
+    int epi;
+};
+int pgv_launch_gemm(pgv_ctx* ctx, int dtype, const GemmArgs& a, hipStream_t s);

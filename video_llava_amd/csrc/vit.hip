@@ -1,0 +1,182 @@
+// CLIP vision tower: packed weights + forward driver.
+// Replaces `vision_tower(image_tensor, output_hidden_states=True).hidden_states[k]`
+// (video_chatgpt/inference.py:93-94; chat.py:140-143; scripts/save_spatio_temporal_clip_features.py:116-120),
+// i.e. HF CLIPVisionTransformer (HF:clip/modeling_clip.py:594-658) up to encoder layer k.
+#include <string.h>
+
+#include "pgv_common.h"
+#include "weights.h"
+
+int pgv_launch_layernorm(int dtype, const float* x, const float* g, const float* b, float eps, void* y, int rows, int cols, hipStream_t s);
+int pgv_launch_embed_ln(const float* pe, const float* cls, const float* pos, const float* g, const float* b, float eps, float* out,
+                        int rows, int tokens, int cols, hipStream_t s);
+int pgv_launch_cast(int dtype, const float* x, void* y, size_t n, hipStream_t s);
+int pgv_launch_im2col(const void* pix, void* a0, int T, int S, int g, int p, int Kp, hipStream_t s);
+int pgv_launch_vit_attn(pgv_ctx* ctx, int dtype, const void* qkv, int ld, void* out, int ldo, int T, int N, int C, int heads, hipStream_t s);
+
+struct VitLayer {
+    float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    void *wqkv, *wo, *w1, *w2;
+    float *bqkv, *bo, *b1, *b2;
+};
+
+struct pgv_vit {
+    pgv_ctx* ctx;
+    pgv_vit_config cfg;
+    int dtype;
+    int grid, patches, tokens, Kp;
+    char* blob = nullptr;
+    size_t blob_bytes = 0;
+    void* patch_w;
+    float *cls, *pos, *pre_g, *pre_b;
+    std::vector<VitLayer> layers;
+    std::set<std::string> loaded;
+    int expected = 0;
+    int max_chunk_frames = 400;
+};
+
+extern "C" int pgv_vit_create(pgv_ctx* ctx, const pgv_vit_config* cfg, int dtype, pgv_vit** out) {
+    PGV_CHECK(ctx && cfg && out, "pgv_vit_create: null argument");
+    PGV_CHECK(dtype == PGV_F16 || dtype == PGV_BF16, "pgv_vit_create: dtype must be PGV_F16 or PGV_BF16");
+    PGV_CHECK(cfg->hidden == 1024, "pgv_vit_create: CLIP width must be 1024 (video_chatgpt/model/video_chatgpt.py:106 hard-codes it); got %d", cfg->hidden);
+    PGV_CHECK(cfg->heads * 64 == cfg->hidden, "pgv_vit_create: head_dim must be 64");
+    PGV_CHECK(cfg->inter % 256 == 0 && cfg->inter > 0, "pgv_vit_create: intermediate size must be a multiple of 256");
+    PGV_CHECK(cfg->patch > 0 && cfg->patch % 2 == 0 && cfg->image % cfg->patch == 0, "pgv_vit_create: image %d / patch %d unsupported", cfg->image, cfg->patch);
+    PGV_CHECK(cfg->layers > 0, "pgv_vit_create: layers must be positive");
+    pgv_vit* v = new pgv_vit();
+    v->ctx = ctx; v->cfg = *cfg; v->dtype = dtype;
+    v->grid = cfg->image / cfg->patch; v->patches = v->grid * v->grid; v->tokens = v->patches + 1;
+    v->Kp = (3 * cfg->patch * cfg->patch + 63) / 64 * 64;
+    const size_t C = cfg->hidden, I = cfg->inter, L = cfg->layers;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += pgv_align(bytes); return o; };
+    const size_t o_patch = take(C * v->Kp * 2), o_cls = take(C * 4), o_pos = take((size_t)v->tokens * C * 4), o_pg = take(C * 4), o_pb = take(C * 4);
+    struct LO { size_t ln1g, ln1b, ln2g, ln2b, wqkv, wo, w1, w2, bqkv, bo, b1, b2; };
+    std::vector<LO> lo(L);
+    for (size_t i = 0; i < L; ++i) {
+        lo[i].ln1g = take(C * 4); lo[i].ln1b = take(C * 4); lo[i].ln2g = take(C * 4); lo[i].ln2b = take(C * 4);
+        lo[i].wqkv = take(3 * C * C * 2); lo[i].wo = take(C * C * 2); lo[i].w1 = take(I * C * 2); lo[i].w2 = take(C * I * 2);
+        lo[i].bqkv = take(3 * C * 4); lo[i].bo = take(C * 4); lo[i].b1 = take(I * 4); lo[i].b2 = take(C * 4);
+    }
+    hipError_t e = hipMalloc((void**)&v->blob, off);
+    if (e != hipSuccess) { delete v; pgv_set_error("pgv_vit_create: hipMalloc(%zu MiB): %s", off >> 20, hipGetErrorString(e)); return PGV_ENOMEM; }
+    v->blob_bytes = off;
+    char* b = v->blob;
+    v->patch_w = b + o_patch; v->cls = (float*)(b + o_cls); v->pos = (float*)(b + o_pos); v->pre_g = (float*)(b + o_pg); v->pre_b = (float*)(b + o_pb);
+    v->layers.resize(L);
+    for (size_t i = 0; i < L; ++i) {
+        VitLayer& l = v->layers[i];
+        l.ln1_g = (float*)(b + lo[i].ln1g); l.ln1_b = (float*)(b + lo[i].ln1b); l.ln2_g = (float*)(b + lo[i].ln2g); l.ln2_b = (float*)(b + lo[i].ln2b);
+        l.wqkv = b + lo[i].wqkv; l.wo = b + lo[i].wo; l.w1 = b + lo[i].w1; l.w2 = b + lo[i].w2;
+        l.bqkv = (float*)(b + lo[i].bqkv); l.bo = (float*)(b + lo[i].bo); l.b1 = (float*)(b + lo[i].b1); l.b2 = (float*)(b + lo[i].b2);
+    }
+    v->expected = 5 + 16 * (int)L;   // post_layernorm is accepted but not needed for hidden_states
+    *out = v;
+    return PGV_OK;
+}
+
+extern "C" void pgv_vit_destroy(pgv_vit* vit) {
+    if (!vit) return;
+    if (vit->blob) (void)hipFree(vit->blob);
+    delete vit;
+}
+
+extern "C" int pgv_vit_missing(const pgv_vit* vit) { return vit ? vit->expected - (int)vit->loaded.size() : -1; }
+
+extern "C" int pgv_vit_load_tensor(pgv_vit* v, const char* name_in, const void* data, int src_dtype, int on_device, void* stream) {
+    PGV_CHECK(v && name_in && data, "pgv_vit_load_tensor: null argument");
+    std::string name(name_in);
+    if (name.rfind("vision_model.", 0) == 0) name = name.substr(13);
+    const long long C = v->cfg.hidden, I = v->cfg.inter;
+    PackDst d;
+    bool counted = true;
+    if (name == "embeddings.class_embedding") { d.ptr = v->cls; d.rows = 1; d.cols = C; }
+    else if (name == "embeddings.patch_embedding.weight") { d.ptr = v->patch_w; d.dst_dtype = v->dtype; d.rows = C; d.cols = 3 * v->cfg.patch * v->cfg.patch; d.dst_stride = v->Kp; }
+    else if (name == "embeddings.position_embedding.weight") { d.ptr = v->pos; d.rows = v->tokens; d.cols = C; }
+    else if (name == "embeddings.position_ids") return PGV_OK;
+    else if (name == "pre_layrnorm.weight") { d.ptr = v->pre_g; d.rows = 1; d.cols = C; }
+    else if (name == "pre_layrnorm.bias") { d.ptr = v->pre_b; d.rows = 1; d.cols = C; }
+    else if (name == "post_layernorm.weight" || name == "post_layernorm.bias") return PGV_OK;
+    else if (name.rfind("encoder.layers.", 0) == 0) {
+        const char* p = name.c_str() + 15;
+        char* end = nullptr;
+        long li = strtol(p, &end, 10);
+        if (end == p || *end != '.' || li < 0 || li >= v->cfg.layers) { pgv_set_error("pgv_vit_load_tensor: bad layer index in '%s'", name_in); return PGV_ENAME; }
+        std::string rest(end + 1);
+        VitLayer& l = v->layers[li];
+        auto vec = [&](float* ptr, long long n) { d.ptr = ptr; d.rows = 1; d.cols = n; };
+        auto mat = [&](void* ptr, long long r, long long c, long long roff) { d.ptr = ptr; d.dst_dtype = v->dtype; d.rows = r; d.cols = c; d.row_off = roff; };
+        if (rest == "self_attn.q_proj.weight") mat(l.wqkv, C, C, 0);
+        else if (rest == "self_attn.k_proj.weight") mat(l.wqkv, C, C, C);
+        else if (rest == "self_attn.v_proj.weight") mat(l.wqkv, C, C, 2 * C);
+        else if (rest == "self_attn.q_proj.bias") vec(l.bqkv, C);
+        else if (rest == "self_attn.k_proj.bias") vec(l.bqkv + C, C);
+        else if (rest == "self_attn.v_proj.bias") vec(l.bqkv + 2 * C, C);
+        else if (rest == "self_attn.out_proj.weight") mat(l.wo, C, C, 0);
+        else if (rest == "self_attn.out_proj.bias") vec(l.bo, C);
+        else if (rest == "layer_norm1.weight") vec(l.ln1_g, C);
+        else if (rest == "layer_norm1.bias") vec(l.ln1_b, C);
+        else if (rest == "layer_norm2.weight") vec(l.ln2_g, C);
+        else if (rest == "layer_norm2.bias") vec(l.ln2_b, C);
+        else if (rest == "mlp.fc1.weight") mat(l.w1, I, C, 0);
+        else if (rest == "mlp.fc1.bias") vec(l.b1, I);
+        else if (rest == "mlp.fc2.weight") mat(l.w2, C, I, 0);
+        else if (rest == "mlp.fc2.bias") vec(l.b2, C);
+        else { pgv_set_error("pgv_vit_load_tensor: unexpected key '%s'", name_in); return PGV_ENAME; }
+    } else { pgv_set_error("pgv_vit_load_tensor: unexpected key '%s'", name_in); return PGV_ENAME; }
+    if (d.dst_stride == 0) d.dst_stride = d.cols;
+    PGV_TRY(pgv_pack_tensor(d, data, src_dtype, on_device, (hipStream_t)stream));
+    if (counted) v->loaded.insert(name);
+    return PGV_OK;
+}
+
+extern "C" int pgv_vit_forward(pgv_ctx* ctx, pgv_vit* v, const void* d_pixels, int T, int n_layers, void* d_hidden, void* stream) {
+    PGV_CHECK(ctx && v && d_pixels && d_hidden, "pgv_vit_forward: null argument");
+    PGV_CHECK(T > 0, "pgv_vit_forward: T must be positive (got %d)", T);
+    PGV_CHECK(n_layers >= 0 && n_layers <= v->cfg.layers, "pgv_vit_forward: n_layers %d outside [0, %d]", n_layers, v->cfg.layers);
+    if (pgv_vit_missing(v) != 0) { pgv_set_error("pgv_vit_forward: %d weight tensors not loaded", pgv_vit_missing(v)); return PGV_ESTATE; }
+    hipStream_t s = (hipStream_t)stream;
+    const int C = v->cfg.hidden, I = v->cfg.inter, N = v->tokens, P = v->patches, S = v->cfg.image;
+    const int Tc_max = T < v->max_chunk_frames ? T : v->max_chunk_frames;
+    const size_t Mmax = (size_t)Tc_max * N;
+    const size_t b_resid = pgv_align(Mmax * C * 4), b_xn = pgv_align(Mmax * C * 2), b_qkv = pgv_align(Mmax * 3 * C * 2), b_ao = pgv_align(Mmax * C * 2),
+                 b_h = pgv_align(Mmax * I * 2 > (size_t)Tc_max * P * ((size_t)v->Kp * 2 + C * 4) + 512 ? Mmax * I * 2 : (size_t)Tc_max * P * ((size_t)v->Kp * 2 + C * 4) + 512);
+    PGV_TRY(pgv_ws_reserve(ctx, b_resid + b_xn + b_qkv + b_ao + b_h));
+    float* resid = (float*)pgv_ws_alloc(ctx, b_resid);
+    char* xn = (char*)pgv_ws_alloc(ctx, b_xn);
+    char* qkv = (char*)pgv_ws_alloc(ctx, b_qkv);
+    char* ao = (char*)pgv_ws_alloc(ctx, b_ao);
+    char* hbuf = (char*)pgv_ws_alloc(ctx, b_h);
+    PGV_CHECK(resid && xn && qkv && ao && hbuf, "pgv_vit_forward: workspace exhausted");
+
+    for (int t0 = 0; t0 < T; t0 += Tc_max) {
+        const int Tc = (T - t0) < Tc_max ? (T - t0) : Tc_max;
+        const int M = Tc * N;
+        const char* pix = (const char*)d_pixels + (size_t)t0 * 3 * S * S * 2;
+        // patch conv as GEMM: [Tc*P, Kp] x [C, Kp]^T -> fp32 [Tc*P, C]
+        char* a0 = hbuf;
+        float* pe = (float*)(hbuf + pgv_align((size_t)Tc * P * v->Kp * 2));
+        PGV_TRY(pgv_launch_im2col(pix, a0, Tc, S, v->grid, v->cfg.patch, v->Kp, s));
+        GemmArgs g{};
+        g.A = a0; g.lda = v->Kp; g.W = v->patch_w; g.ldw = v->Kp; g.bias = nullptr; g.C = pe; g.ldc = C; g.M = Tc * P; g.N = C; g.K = v->Kp; g.epi = PGV_EPI_F32;
+        PGV_TRY(pgv_launch_gemm(ctx, v->dtype, g, s));
+        PGV_TRY(pgv_launch_embed_ln(pe, v->cls, v->pos, v->pre_g, v->pre_b, v->cfg.eps, resid, M, N, C, s));
+        for (int li = 0; li < n_layers; ++li) {
+            const VitLayer& l = v->layers[li];
+            PGV_TRY(pgv_launch_layernorm(v->dtype, resid, l.ln1_g, l.ln1_b, v->cfg.eps, xn, M, C, s));
+            g = GemmArgs{}; g.A = xn; g.lda = C; g.W = l.wqkv; g.ldw = C; g.bias = l.bqkv; g.C = qkv; g.ldc = 3 * C; g.M = M; g.N = 3 * C; g.K = C; g.epi = PGV_EPI_BIAS;
+            PGV_TRY(pgv_launch_gemm(ctx, v->dtype, g, s));
+            PGV_TRY(pgv_launch_vit_attn(ctx, v->dtype, qkv, 3 * C, ao, C, Tc, N, C, v->cfg.heads, s));
+            g = GemmArgs{}; g.A = ao; g.lda = C; g.W = l.wo; g.ldw = C; g.bias = l.bo; g.C = resid; g.ldc = C; g.M = M; g.N = C; g.K = C; g.epi = PGV_EPI_BIAS_RESID;
+            PGV_TRY(pgv_launch_gemm(ctx, v->dtype, g, s));
+            PGV_TRY(pgv_launch_layernorm(v->dtype, resid, l.ln2_g, l.ln2_b, v->cfg.eps, xn, M, C, s));
+            g = GemmArgs{}; g.A = xn; g.lda = C; g.W = l.w1; g.ldw = C; g.bias = l.b1; g.C = hbuf; g.ldc = I; g.M = M; g.N = I; g.K = C; g.epi = PGV_EPI_BIAS_QGELU;
+            PGV_TRY(pgv_launch_gemm(ctx, v->dtype, g, s));
+            g = GemmArgs{}; g.A = hbuf; g.lda = I; g.W = l.w2; g.ldw = I; g.bias = l.b2; g.C = resid; g.ldc = C; g.M = M; g.N = C; g.K = I; g.epi = PGV_EPI_BIAS_RESID;
+            PGV_TRY(pgv_launch_gemm(ctx, v->dtype, g, s));
+        }
+        PGV_TRY(pgv_launch_cast(v->dtype, resid, (char*)d_hidden + (size_t)t0 * N * C * 2, (size_t)M * C, s));
+    }
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}

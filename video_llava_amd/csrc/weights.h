@@ -1,0 +1,23 @@
+// Weight packing helpers shared by vit.hip and llm.hip: convert one checkpoint tensor (fp32/fp16/bf16,
+// host or device) into the library's packed device storage (16-bit GEMM operands, fp32 biases / norm
+// parameters), optionally re-mapping rows (fused qkv, interleaved gate/up) and zero-padding columns.
+#pragma once
+#include <set>
+#include <string>
+
+#include "pgv_common.h"
+
+struct PackDst {
+    void* ptr = nullptr;      // destination base
+    int dst_dtype = PGV_F32;  // PGV_F16 / PGV_BF16 / PGV_F32
+    long long rows = 0, cols = 0;   // logical source shape (rows x cols, row-major contiguous)
+    long long dst_stride = 0;       // destination row stride (elements) >= cols; [cols, dst_stride) is zero-filled
+    long long row_blk = 0;          // 0: dst_row = r + row_off;  else dst_row = (r / row_blk) * blk_stride + r % row_blk + row_off
+    long long blk_stride = 0;
+    long long row_off = 0;
+};
+
+// Enqueue the conversion on `s`.  Host sources are staged through a temporary device buffer (synchronous).
+int pgv_pack_tensor(const PackDst& d, const void* data, int src_dtype, int on_device, hipStream_t s);
+
+inline size_t pgv_dtype_size(int dt) { return dt == PGV_F32 ? 4 : 2; }
