@@ -132,18 +132,26 @@ void pgv_llm_destroy(pgv_llm *llm);
  * projector checkpoint carries the rows of the added video tokens, train/llava_trainer.py:34). */
 int pgv_llm_load_tensor(pgv_llm *llm, const char *name, const void *data, int src_dtype, int on_device, void *stream);
 int pgv_llm_missing(const pgv_llm *llm);
+/* Load `nrows` rows starting at `row0` of "model.embed_tokens.weight" or "lm_head.weight" (checkpoints whose
+ * vocabulary is smaller than the resized model, eval/model_utils.py:119-127). */
+int pgv_llm_load_rows(pgv_llm *llm, const char *name, const void *data, int src_dtype, int on_device, int row0, int nrows, void *stream);
+/* model.resize_token_embeddings(n) (eval/model_utils.py:119): the handle is allocated with 64 spare vocabulary
+ * rows; growing within them zero-fills the new embed / lm_head rows (the projector checkpoint then overwrites them). */
+int pgv_llm_resize_vocab(pgv_llm *llm, int new_vocab, void *stream);
+int pgv_llm_vocab(const pgv_llm *llm);
 
 int pgv_kv_create(pgv_ctx *ctx, pgv_llm *llm, int batch, int max_seq, pgv_kv **out);
 void pgv_kv_destroy(pgv_kv *kv);
 
 /* Prefill (the `input_ids.shape[1] != 1` branch, video_chatgpt/model/video_chatgpt.py:100-175 and
  * :225-226): embed + splice projected video rows + decoder stack + lm_head on the LAST position of
- * each sequence.  Sequences are ragged: h_seq_lens[b] tokens each, concatenated in d_ids.
+ * each sequence.  Sequences are ragged: h_seq_lens[b] tokens each, concatenated in h_ids (host: the
+ * tokenizer output never lives on the device, and the row map of the splice is built from it).
  * d_video [B, V, hidden] = mm_projector output, 16-bit (or NULL); h_vid_pos[b] = index of <vid_start>
  * in sequence b, or -1 for a text-only sample (rows (pos, pos+V] are replaced -- the caller has already
  * validated the placeholder run on the host, raising the reference's ValueErrors).
  * Outputs (either may be NULL): d_logits [B, vocab] fp32, d_next [B] int32 greedy argmax. */
-int pgv_llm_prefill(pgv_ctx *ctx, pgv_llm *llm, pgv_kv *kv, const int32_t *d_ids, const int32_t *h_seq_lens, int B,
+int pgv_llm_prefill(pgv_ctx *ctx, pgv_llm *llm, pgv_kv *kv, const int32_t *h_ids, const int32_t *h_seq_lens, int B,
                     const void *d_video, int V, const int32_t *h_vid_pos, float *d_logits, int32_t *d_next, void *stream);
 
 /* One decode step for all B sequences (the `input_ids.shape[1] == 1` branch, :103): consumes

@@ -132,7 +132,8 @@ def test_pool_full_size_and_strided_view(ctx):
     assert d.max() <= 2 ** -10 and float((d == 0).float().mean()) > 0.98
     # linearity property at full size: pool(2x) == 2*pool(x) exactly (power-of-two scaling is exact in fp16/fp32)
     out2 = ctx.st_pool((view * 2).contiguous())
-    assert torch.equal(out2, out * 2)
+    normal = out.abs() > 2 ** -13                      # doubling commutes with rounding outside fp16's subnormal range
+    assert torch.equal(out2[normal], (out * 2)[normal])
     with pytest.raises(ValueError):
         ctx.st_pool(torch.zeros(101, 4, 1024, dtype=torch.float16, device=DEV))   # reference never truncates; we refuse
 

@@ -55,6 +55,9 @@ PROTOTYPES = {
     "pgv_llm_destroy": (None, [_vp]),
     "pgv_llm_load_tensor": (_i, [_vp, C.c_char_p, _vp, _i, _i, _vp]),
     "pgv_llm_missing": (_i, [_vp]),
+    "pgv_llm_load_rows": (_i, [_vp, C.c_char_p, _vp, _i, _i, _i, _i, _vp]),
+    "pgv_llm_resize_vocab": (_i, [_vp, _i, _vp]),
+    "pgv_llm_vocab": (_i, [_vp]),
     "pgv_kv_create": (_i, [_vp, _vp, _i, _i, C.POINTER(_vp)]),
     "pgv_kv_destroy": (None, [_vp]),
     "pgv_kv_len": (_i, [_vp, _i]),

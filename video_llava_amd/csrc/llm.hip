@@ -1,17 +1,375 @@
-// TEMPORARY stubs (replaced by the real decoder in the next commit).
-#include "pgv_common.h"
-#define NOTYET(name) pgv_set_error(name ": not implemented yet"); return PGV_ESTATE
-extern "C" int pgv_llm_create(pgv_ctx*, const pgv_llm_config*, int, pgv_llm**) { NOTYET("pgv_llm_create"); }
-extern "C" void pgv_llm_destroy(pgv_llm*) {}
-extern "C" int pgv_llm_load_tensor(pgv_llm*, const char*, const void*, int, int, void*) { NOTYET("pgv_llm_load_tensor"); }
-extern "C" int pgv_llm_missing(const pgv_llm*) { return -1; }
-extern "C" int pgv_kv_create(pgv_ctx*, pgv_llm*, int, int, pgv_kv**) { NOTYET("pgv_kv_create"); }
-extern "C" void pgv_kv_destroy(pgv_kv*) {}
-extern "C" int pgv_kv_len(const pgv_kv*, int) { return -1; }
-extern "C" int pgv_llm_prefill(pgv_ctx*, pgv_llm*, pgv_kv*, const int32_t*, const int32_t*, int, const void*, int, const int32_t*, float*, int32_t*, void*) { NOTYET("pgv_llm_prefill"); }
-extern "C" int pgv_llm_decode(pgv_ctx*, pgv_llm*, pgv_kv*, const int32_t*, float*, int32_t*, void*) { NOTYET("pgv_llm_decode"); }
-extern "C" int pgv_llm_decode_greedy(pgv_ctx*, pgv_llm*, pgv_kv*, const int32_t*, int, int, int32_t*, void*) { NOTYET("pgv_llm_decode_greedy"); }
+// mm_projector + LLaMA decoder host side: packed weights, KV cache, prefill / decode drivers.
+// Replaces VideoChatGPTLlamaForCausalLM.forward (video_chatgpt/model/video_chatgpt.py:193-251 -> :82-175 -> HF LlamaModel)
+// as driven by model.generate (video_chatgpt/inference.py:105-112).
+#include <math.h>
+#include <string.h>
 
+#include "pgv_common.h"
+#include "weights.h"
+
+int pgv_launch_rmsnorm(int dtype, const float* x, const float* g, float eps, void* y, int rows, int cols, hipStream_t s);
+int pgv_launch_embed_splice(int dtype, const int* row_src, const void* embed, const void* video, float* resid, int M, int H, hipStream_t s);
+int pgv_launch_embed_tok(int dtype, const int* tok, const void* embed, float* resid, int B, int H, hipStream_t s);
+int pgv_launch_gather_rows(const float* src, const int* rows, float* dst, int B, int H, hipStream_t s);
+int pgv_launch_rope_kv_write(int dtype, void* qkv, const int* row_b, const int* row_pos, const void* rope, void* Kc, void* Vc, int M, int H,
+                             int heads, int max_seq, hipStream_t s);
+int pgv_launch_prefill_attn(pgv_ctx* ctx, int dtype, const void* qkv, void* out, const void* Kc, const void* Vc, const int* cu, int B, int max_len,
+                            int H, int heads, int max_seq, double flops, hipStream_t s);
+int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void* x, int ldx, void* out, int ldo, int N, int K, int B, hipStream_t s);
+int pgv_launch_decode_attn(pgv_ctx* ctx, int dtype, const void* qkv, const int* pos, const void* rope, void* Kc, void* Vc, void* out, int B, int H,
+                           int heads, int max_seq, double bytes, hipStream_t s);
+int pgv_launch_argmax(const float* logits, int V, int B, int* next, int* pos, int* step, int* hist, int hist_stride, int* done, int eos, int flags,
+                      hipStream_t s);
+enum { GV_STORE16 = 0, GV_RESID = 1, GV_SWIGLU = 2, GV_F32 = 3 };
+enum { AM_INC_POS = 1, AM_RECORD = 2 };
+
+constexpr int kMaxPos = 4096;   // max_position_embeddings of LLaVA-1.5 / Vicuna-1.5
+constexpr int kHD = 128;
+
+struct LlmLayer {
+    float *in_g, *post_g;
+    void *wqkv, *wo, *wgu, *wdown;
+};
+
+struct pgv_llm {
+    pgv_ctx* ctx;
+    pgv_llm_config cfg;
+    int dtype;
+    char* blob = nullptr;
+    size_t blob_bytes = 0;
+    void *embed, *lm_head;
+    float* norm_g;
+    float* rope;   // float2 [kMaxPos][64]
+    std::vector<LlmLayer> layers;
+    std::set<std::string> loaded;
+    int expected = 0;
+    int vocab_cap = 0;   // allocated rows of embed / lm_head (cfg.vocab at creation + 64 spare)
+};
+
+struct pgv_kv {
+    pgv_llm* llm;
+    int B, max_seq;
+    char* blob = nullptr;
+    std::vector<void*> Kc, Vc;          // per layer [B][heads][max_seq][128]
+    // fixed-address decode buffers (so a decode step can be captured into a hipGraph)
+    float* resid; void* xn; void* qkv; void* ao; void* act; float* logits;
+    int *d_pos, *d_cur, *d_step, *d_done, *d_hist;
+    std::vector<int> h_len;
+    std::vector<int> h_meta;           // staging for prefill row maps (kept alive across the async copy)
+    int active = 0;                     // sequences of the last prefill
+};
+
+extern "C" int pgv_llm_create(pgv_ctx* ctx, const pgv_llm_config* cfg, int dtype, pgv_llm** out) {
+    PGV_CHECK(ctx && cfg && out, "pgv_llm_create: null argument");
+    PGV_CHECK(dtype == PGV_F16 || dtype == PGV_BF16, "pgv_llm_create: dtype must be PGV_F16 or PGV_BF16");
+    PGV_CHECK(cfg->heads * kHD == cfg->hidden, "pgv_llm_create: head_dim must be 128 (hidden %d, heads %d)", cfg->hidden, cfg->heads);
+    PGV_CHECK(cfg->hidden % 256 == 0, "pgv_llm_create: hidden must be a multiple of 256");
+    PGV_CHECK(cfg->inter % 64 == 0, "pgv_llm_create: intermediate size must be a multiple of 64");
+    PGV_CHECK(cfg->vocab > 0 && cfg->layers >= 0, "pgv_llm_create: bad vocab/layers");
+    pgv_llm* m = new pgv_llm();
+    m->ctx = ctx; m->cfg = *cfg; m->dtype = dtype;
+    m->vocab_cap = cfg->vocab + 64;
+    const size_t H = cfg->hidden, I = cfg->inter, V = m->vocab_cap, L = cfg->layers;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += pgv_align(bytes); return o; };
+    const size_t o_embed = take(V * H * 2), o_head = take(V * H * 2), o_norm = take(H * 4), o_rope = take((size_t)kMaxPos * 64 * 8);
+    struct LO { size_t in_g, post_g, wqkv, wo, wgu, wdown; };
+    std::vector<LO> lo(L);
+    for (size_t i = 0; i < L; ++i) {
+        lo[i].in_g = take(H * 4); lo[i].post_g = take(H * 4);
+        lo[i].wqkv = take(3 * H * H * 2); lo[i].wo = take(H * H * 2); lo[i].wgu = take(2 * I * H * 2); lo[i].wdown = take(H * I * 2);
+    }
+    hipError_t e = hipMalloc((void**)&m->blob, off);
+    if (e != hipSuccess) { delete m; pgv_set_error("pgv_llm_create: hipMalloc(%zu MiB): %s", off >> 20, hipGetErrorString(e)); return PGV_ENOMEM; }
+    m->blob_bytes = off;
+    char* b = m->blob;
+    m->embed = b + o_embed; m->lm_head = b + o_head; m->norm_g = (float*)(b + o_norm); m->rope = (float*)(b + o_rope);
+    m->layers.resize(L);
+    for (size_t i = 0; i < L; ++i) {
+        LlmLayer& l = m->layers[i];
+        l.in_g = (float*)(b + lo[i].in_g); l.post_g = (float*)(b + lo[i].post_g);
+        l.wqkv = b + lo[i].wqkv; l.wo = b + lo[i].wo; l.wgu = b + lo[i].wgu; l.wdown = b + lo[i].wdown;
+    }
+    // RoPE table exactly as LlamaRotaryEmbedding (HF:llama/modeling_llama.py:96-126): fp32 inv_freq, fp32 angle, fp32 cos/sin
+    std::vector<float> tab((size_t)kMaxPos * 64 * 2);
+    for (int j = 0; j < 64; ++j) {
+        const float inv = 1.0f / powf(cfg->rope_theta, (float)(2 * j) / (float)kHD);
+        for (int p = 0; p < kMaxPos; ++p) {
+            const float ang = (float)p * inv;
+            tab[((size_t)p * 64 + j) * 2] = cosf(ang);
+            tab[((size_t)p * 64 + j) * 2 + 1] = sinf(ang);
+        }
+    }
+    e = hipMemcpy(m->rope, tab.data(), tab.size() * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(m->blob); delete m; pgv_set_error("pgv_llm_create: rope upload: %s", hipGetErrorString(e)); return PGV_EHIP; }
+    m->expected = 3 + 9 * (int)L;
+    *out = m;
+    return PGV_OK;
+}
+
+extern "C" void pgv_llm_destroy(pgv_llm* llm) {
+    if (!llm) return;
+    if (llm->blob) (void)hipFree(llm->blob);
+    delete llm;
+}
+
+extern "C" int pgv_llm_missing(const pgv_llm* llm) { return llm ? llm->expected - (int)llm->loaded.size() : -1; }
+extern "C" int pgv_llm_vocab(const pgv_llm* llm) { return llm ? llm->cfg.vocab : -1; }
+
+extern "C" int pgv_llm_resize_vocab(pgv_llm* m, int new_vocab, void* stream) {
+    PGV_CHECK(m != nullptr, "pgv_llm_resize_vocab: null model");
+    PGV_CHECK(new_vocab >= 1 && new_vocab <= m->vocab_cap, "pgv_llm_resize_vocab: %d outside [1,%d] (64 spare rows are allocated at creation)", new_vocab, m->vocab_cap);
+    const size_t H = m->cfg.hidden;
+    if (new_vocab > m->cfg.vocab) {
+        const size_t off = (size_t)m->cfg.vocab * H * 2, bytes = (size_t)(new_vocab - m->cfg.vocab) * H * 2;
+        PGV_HIP(hipMemsetAsync((char*)m->embed + off, 0, bytes, (hipStream_t)stream));
+        PGV_HIP(hipMemsetAsync((char*)m->lm_head + off, 0, bytes, (hipStream_t)stream));
+    }
+    m->cfg.vocab = new_vocab;
+    return PGV_OK;
+}
+
+extern "C" int pgv_llm_load_rows(pgv_llm* m, const char* name, const void* data, int src_dtype, int on_device, int row0, int nrows, void* stream) {
+    PGV_CHECK(m && name && data, "pgv_llm_load_rows: null argument");
+    PGV_CHECK(row0 >= 0 && nrows >= 1 && row0 + nrows <= m->cfg.vocab, "pgv_llm_load_rows: rows [%d,%d) outside the vocabulary (%d)", row0, row0 + nrows, m->cfg.vocab);
+    PackDst d;
+    d.dst_dtype = m->dtype; d.rows = nrows; d.cols = m->cfg.hidden; d.dst_stride = d.cols; d.row_off = row0;
+    if (!strcmp(name, "model.embed_tokens.weight")) d.ptr = m->embed;
+    else if (!strcmp(name, "lm_head.weight")) d.ptr = m->lm_head;
+    else { pgv_set_error("pgv_llm_load_rows: '%s' is not a vocabulary matrix", name); return PGV_ENAME; }
+    PGV_TRY(pgv_pack_tensor(d, data, src_dtype, on_device, (hipStream_t)stream));
+    m->loaded.insert(name);
+    return PGV_OK;
+}
+
+extern "C" int pgv_llm_load_tensor(pgv_llm* m, const char* name_in, const void* data, int src_dtype, int on_device, void* stream) {
+    PGV_CHECK(m && name_in && data, "pgv_llm_load_tensor: null argument");
+    std::string name(name_in);
+    const long long H = m->cfg.hidden, I = m->cfg.inter, V = m->cfg.vocab;
+    PackDst d;
+    auto vec = [&](float* ptr, long long n) { d.ptr = ptr; d.rows = 1; d.cols = n; };
+    auto mat = [&](void* ptr, long long r, long long c, long long roff) { d.ptr = ptr; d.dst_dtype = m->dtype; d.rows = r; d.cols = c; d.row_off = roff; };
+    if (name == "model.embed_tokens.weight") mat(m->embed, V, H, 0);
+    else if (name == "lm_head.weight") mat(m->lm_head, V, H, 0);
+    else if (name == "model.norm.weight") vec(m->norm_g, H);
+    else if (name.rfind("model.layers.", 0) == 0) {
+        const char* p = name.c_str() + 13;
+        char* end = nullptr;
+        long li = strtol(p, &end, 10);
+        if (end == p || *end != '.' || li < 0 || li >= m->cfg.layers) { pgv_set_error("pgv_llm_load_tensor: bad layer index in '%s'", name_in); return PGV_ENAME; }
+        std::string rest(end + 1);
+        LlmLayer& l = m->layers[li];
+        if (rest == "self_attn.q_proj.weight") mat(l.wqkv, H, H, 0);
+        else if (rest == "self_attn.k_proj.weight") mat(l.wqkv, H, H, H);
+        else if (rest == "self_attn.v_proj.weight") mat(l.wqkv, H, H, 2 * H);
+        else if (rest == "self_attn.o_proj.weight") mat(l.wo, H, H, 0);
+        else if (rest == "mlp.gate_proj.weight") { mat(l.wgu, I, H, 0); d.row_blk = 32; d.blk_stride = 64; }       // [32 gate | 32 up] per 64 rows
+        else if (rest == "mlp.up_proj.weight") { mat(l.wgu, I, H, 32); d.row_blk = 32; d.blk_stride = 64; }
+        else if (rest == "mlp.down_proj.weight") mat(l.wdown, H, I, 0);
+        else if (rest == "input_layernorm.weight") vec(l.in_g, H);
+        else if (rest == "post_attention_layernorm.weight") vec(l.post_g, H);
+        else if (rest == "self_attn.rotary_emb.inv_freq") return PGV_OK;
+        else { pgv_set_error("pgv_llm_load_tensor: unexpected key '%s'", name_in); return PGV_ENAME; }
+    } else { pgv_set_error("pgv_llm_load_tensor: unexpected key '%s'", name_in); return PGV_ENAME; }
+    d.dst_stride = d.cols;
+    PGV_TRY(pgv_pack_tensor(d, data, src_dtype, on_device, (hipStream_t)stream));
+    m->loaded.insert(name);
+    return PGV_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// KV cache
+// ---------------------------------------------------------------------------------------------
+extern "C" int pgv_kv_create(pgv_ctx* ctx, pgv_llm* llm, int batch, int max_seq, pgv_kv** out) {
+    PGV_CHECK(ctx && llm && out, "pgv_kv_create: null argument");
+    PGV_CHECK(batch >= 1 && batch <= 16, "pgv_kv_create: batch %d outside [1,16] (decode GEMV tiles 16 sequences)", batch);
+    PGV_CHECK(max_seq >= 1 && max_seq <= kMaxPos, "pgv_kv_create: max_seq %d outside [1,%d]", max_seq, kMaxPos);
+    pgv_kv* kv = new pgv_kv();
+    kv->llm = llm; kv->B = batch; kv->max_seq = max_seq;
+    const size_t H = llm->cfg.hidden, I = llm->cfg.inter, V = llm->vocab_cap, L = llm->cfg.layers, B = batch;
+    const size_t per = pgv_align(B * llm->cfg.heads * (size_t)max_seq * kHD * 2);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += pgv_align(bytes); return o; };
+    const size_t o_cache = take(per * 2 * L);
+    const size_t o_resid = take(B * H * 4), o_xn = take(B * H * 2), o_qkv = take(B * 3 * H * 2), o_ao = take(B * H * 2), o_act = take(B * I * 2),
+                 o_logits = take(B * V * 4), o_ints = take((4 * B + B * (size_t)max_seq) * 4);
+    hipError_t e = hipMalloc((void**)&kv->blob, off);
+    if (e != hipSuccess) { delete kv; pgv_set_error("pgv_kv_create: hipMalloc(%zu MiB): %s", off >> 20, hipGetErrorString(e)); return PGV_ENOMEM; }
+    char* b = kv->blob;
+    for (size_t i = 0; i < L; ++i) { kv->Kc.push_back(b + o_cache + per * 2 * i); kv->Vc.push_back(b + o_cache + per * (2 * i + 1)); }
+    kv->resid = (float*)(b + o_resid); kv->xn = b + o_xn; kv->qkv = b + o_qkv; kv->ao = b + o_ao; kv->act = b + o_act; kv->logits = (float*)(b + o_logits);
+    int* ints = (int*)(b + o_ints);
+    kv->d_pos = ints; kv->d_cur = ints + B; kv->d_step = ints + 2 * B; kv->d_done = ints + 3 * B; kv->d_hist = ints + 4 * B;
+    e = hipMemset(ints, 0, (4 * B + B * (size_t)max_seq) * 4);
+    if (e != hipSuccess) { (void)hipFree(kv->blob); delete kv; pgv_set_error("pgv_kv_create: memset: %s", hipGetErrorString(e)); return PGV_EHIP; }
+    kv->h_len.assign(batch, 0);
+    *out = kv;
+    return PGV_OK;
+}
+
+extern "C" void pgv_kv_destroy(pgv_kv* kv) {
+    if (!kv) return;
+    if (kv->blob) (void)hipFree(kv->blob);
+    delete kv;
+}
+
+extern "C" int pgv_kv_len(const pgv_kv* kv, int b) { return (kv && b >= 0 && b < kv->B) ? kv->h_len[b] : -1; }
+
+// ---------------------------------------------------------------------------------------------
+// shared tail: final norm + lm_head + argmax on kv->resid [B,H]
+// ---------------------------------------------------------------------------------------------
+static int lm_head_and_pick(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int B, int eos, int flags, hipStream_t s) {
+    const int H = m->cfg.hidden, V = m->cfg.vocab;
+    PGV_TRY(pgv_launch_rmsnorm(m->dtype, kv->resid, m->norm_g, m->cfg.eps, kv->xn, B, H, s));
+    PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_F32, m->lm_head, kv->xn, H, kv->logits, V, V, H, B, s));
+    PGV_TRY(pgv_launch_argmax(kv->logits, V, B, kv->d_cur, kv->d_pos, kv->d_step, kv->d_hist, kv->max_seq, kv->d_done, eos, flags, s));
+    return PGV_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// prefill
+// ---------------------------------------------------------------------------------------------
+extern "C" int pgv_llm_prefill(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, const int32_t* h_ids, const int32_t* h_seq_lens, int B, const void* d_video,
+                               int Vt, const int32_t* h_vid_pos, float* d_logits, int32_t* d_next, void* stream) {
+    PGV_CHECK(ctx && m && kv && h_ids && h_seq_lens, "pgv_llm_prefill: null argument");
+    PGV_CHECK(kv->llm == m, "pgv_llm_prefill: kv cache belongs to another model");
+    PGV_CHECK(B >= 1 && B <= kv->B, "pgv_llm_prefill: batch %d outside [1,%d]", B, kv->B);
+    if (pgv_llm_missing(m) != 0) { pgv_set_error("pgv_llm_prefill: %d weight tensors not loaded", pgv_llm_missing(m)); return PGV_ESTATE; }
+    hipStream_t s = (hipStream_t)stream;
+    const int H = m->cfg.hidden, I = m->cfg.inter, heads = m->cfg.heads, vocab = m->cfg.vocab;
+    int M = 0, max_len = 0;
+    for (int b = 0; b < B; ++b) {
+        PGV_CHECK(h_seq_lens[b] >= 1 && h_seq_lens[b] <= kv->max_seq, "pgv_llm_prefill: sequence %d has %d tokens (cache holds %d)", b, h_seq_lens[b], kv->max_seq);
+        M += h_seq_lens[b];
+        if (h_seq_lens[b] > max_len) max_len = h_seq_lens[b];
+    }
+    // ---- host-built row maps: [row_src | row_b | row_pos | cu (B+1) | last_rows (B) | lens (B)] ----
+    std::vector<int>& meta = kv->h_meta;
+    meta.assign((size_t)3 * M + 3 * B + 1, 0);
+    int* row_src = meta.data(); int* row_b = row_src + M; int* row_pos = row_b + M; int* cu = row_pos + M; int* last = cu + B + 1; int* lens = last + B;
+    int r = 0;
+    for (int b = 0; b < B; ++b) {
+        cu[b] = r;
+        const int vp = (d_video && h_vid_pos) ? h_vid_pos[b] : -1;
+        if (vp >= 0) PGV_CHECK(vp + Vt + 1 < h_seq_lens[b], "pgv_llm_prefill: video run of sequence %d (start %d, %d rows) overruns its %d tokens", b, vp, Vt, h_seq_lens[b]);
+        for (int p = 0; p < h_seq_lens[b]; ++p, ++r) {
+            const int id = h_ids[r];
+            const bool vid = vp >= 0 && p > vp && p <= vp + Vt;
+            if (!vid) PGV_CHECK(id >= 0 && id < vocab, "pgv_llm_prefill: token id %d at row %d outside the vocabulary (%d)", id, r, vocab);
+            row_src[r] = vid ? -(b * Vt + (p - vp - 1) + 1) : id;
+            row_b[r] = b; row_pos[r] = p;
+        }
+        last[b] = r - 1; lens[b] = h_seq_lens[b];
+    }
+    cu[B] = r;
+
+    const size_t b_meta = pgv_align(meta.size() * 4), b_resid = pgv_align((size_t)M * H * 4), b_xn = pgv_align((size_t)M * H * 2),
+                 b_qkv = pgv_align((size_t)M * 3 * H * 2), b_ao = pgv_align((size_t)M * H * 2), b_act = pgv_align((size_t)M * I * 2);
+    PGV_TRY(pgv_ws_reserve(ctx, b_meta + b_resid + b_xn + b_qkv + b_ao + b_act));
+    int* d_meta = (int*)pgv_ws_alloc(ctx, b_meta);
+    float* resid = (float*)pgv_ws_alloc(ctx, b_resid);
+    char* xn = (char*)pgv_ws_alloc(ctx, b_xn);
+    char* qkv = (char*)pgv_ws_alloc(ctx, b_qkv);
+    char* ao = (char*)pgv_ws_alloc(ctx, b_ao);
+    char* act = (char*)pgv_ws_alloc(ctx, b_act);
+    PGV_CHECK(d_meta && resid && xn && qkv && ao && act, "pgv_llm_prefill: workspace exhausted");
+    PGV_HIP(hipMemcpyAsync(d_meta, meta.data(), meta.size() * 4, hipMemcpyHostToDevice, s));
+    const int* d_row_src = d_meta; const int* d_row_b = d_meta + M; const int* d_row_pos = d_row_b + M; const int* d_cu = d_row_pos + M;
+    const int* d_last = d_cu + B + 1; const int* d_lens = d_last + B;
+    PGV_HIP(hipMemcpyAsync(kv->d_pos, d_lens, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+    PGV_HIP(hipMemsetAsync(kv->d_step, 0, (size_t)2 * kv->B * 4, s));      // step + done
+
+    PGV_TRY(pgv_launch_embed_splice(m->dtype, d_row_src, m->embed, d_video, resid, M, H, s));
+    double attn_flops = 0;
+    for (int b = 0; b < B; ++b) attn_flops += 2.0 * (double)h_seq_lens[b] * h_seq_lens[b] * H;   // causal: 4*S^2*H/2
+    for (int li = 0; li < m->cfg.layers; ++li) {
+        const LlmLayer& l = m->layers[li];
+        PGV_TRY(pgv_launch_rmsnorm(m->dtype, resid, l.in_g, m->cfg.eps, xn, M, H, s));
+        GemmArgs g{};
+        g.A = xn; g.lda = H; g.W = l.wqkv; g.ldw = H; g.bias = nullptr; g.C = qkv; g.ldc = 3 * H; g.M = M; g.N = 3 * H; g.K = H; g.epi = PGV_EPI_NONE;
+        PGV_TRY(pgv_launch_gemm(ctx, m->dtype, g, s));
+        PGV_TRY(pgv_launch_rope_kv_write(m->dtype, qkv, d_row_b, d_row_pos, m->rope, kv->Kc[li], kv->Vc[li], M, H, heads, kv->max_seq, s));
+        PGV_TRY(pgv_launch_prefill_attn(ctx, m->dtype, qkv, ao, kv->Kc[li], kv->Vc[li], d_cu, B, max_len, H, heads, kv->max_seq, attn_flops, s));
+        g = GemmArgs{}; g.A = ao; g.lda = H; g.W = l.wo; g.ldw = H; g.C = resid; g.ldc = H; g.M = M; g.N = H; g.K = H; g.epi = PGV_EPI_RESID;
+        PGV_TRY(pgv_launch_gemm(ctx, m->dtype, g, s));
+        PGV_TRY(pgv_launch_rmsnorm(m->dtype, resid, l.post_g, m->cfg.eps, xn, M, H, s));
+        g = GemmArgs{}; g.A = xn; g.lda = H; g.W = l.wgu; g.ldw = H; g.C = act; g.ldc = I; g.M = M; g.N = 2 * I; g.K = H; g.epi = PGV_EPI_SWIGLU;
+        PGV_TRY(pgv_launch_gemm(ctx, m->dtype, g, s));
+        g = GemmArgs{}; g.A = act; g.lda = I; g.W = l.wdown; g.ldw = I; g.C = resid; g.ldc = H; g.M = M; g.N = H; g.K = I; g.epi = PGV_EPI_RESID;
+        PGV_TRY(pgv_launch_gemm(ctx, m->dtype, g, s));
+    }
+    // lm_head only on the last position of every sequence (the reference computes all S positions, video_chatgpt.py:226)
+    PGV_TRY(pgv_launch_gather_rows(resid, d_last, kv->resid, B, H, s));
+    PGV_TRY(lm_head_and_pick(ctx, m, kv, B, -1, 0, s));
+    if (d_logits) PGV_HIP(hipMemcpyAsync(d_logits, kv->logits, (size_t)B * vocab * 4, hipMemcpyDeviceToDevice, s));
+    if (d_next) PGV_HIP(hipMemcpyAsync(d_next, kv->d_cur, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+    for (int b = 0; b < kv->B; ++b) kv->h_len[b] = b < B ? h_seq_lens[b] : 0;
+    kv->active = B;
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// decode
+// ---------------------------------------------------------------------------------------------
+static int decode_step(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int eos, int flags, hipStream_t s) {
+    const int H = m->cfg.hidden, I = m->cfg.inter, heads = m->cfg.heads, B = kv->active;
+    PGV_TRY(pgv_launch_embed_tok(m->dtype, kv->d_cur, m->embed, kv->resid, B, H, s));
+    double kv_bytes = 0;
+    for (int b = 0; b < B; ++b) kv_bytes += 2.0 * 2.0 * (double)(kv->h_len[b] + 1) * H;
+    for (int li = 0; li < m->cfg.layers; ++li) {
+        const LlmLayer& l = m->layers[li];
+        PGV_TRY(pgv_launch_rmsnorm(m->dtype, kv->resid, l.in_g, m->cfg.eps, kv->xn, B, H, s));
+        PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_STORE16, l.wqkv, kv->xn, H, kv->qkv, 3 * H, 3 * H, H, B, s));
+        PGV_TRY(pgv_launch_decode_attn(ctx, m->dtype, kv->qkv, kv->d_pos, m->rope, kv->Kc[li], kv->Vc[li], kv->ao, B, H, heads, kv->max_seq, kv_bytes, s));
+        PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_RESID, l.wo, kv->ao, H, kv->resid, H, H, H, B, s));
+        PGV_TRY(pgv_launch_rmsnorm(m->dtype, kv->resid, l.post_g, m->cfg.eps, kv->xn, B, H, s));
+        PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_SWIGLU, l.wgu, kv->xn, H, kv->act, I, 2 * I, H, B, s));
+        PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_RESID, l.wdown, kv->act, I, kv->resid, H, H, I, B, s));
+    }
+    PGV_TRY(lm_head_and_pick(ctx, m, kv, B, eos, flags, s));
+    for (int b = 0; b < B; ++b) kv->h_len[b] += 1;
+    return PGV_OK;
+}
+
+static int check_decode(pgv_llm* m, pgv_kv* kv, int steps, const char* who) {
+    PGV_CHECK(m && kv && kv->llm == m, "%s: bad model / cache", who);
+    if (kv->active < 1) { pgv_set_error("%s: no prefilled sequences in this cache", who); return PGV_ESTATE; }
+    for (int b = 0; b < kv->active; ++b)
+        PGV_CHECK(kv->h_len[b] + steps <= kv->max_seq, "%s: sequence %d would grow to %d tokens (cache holds %d)", who, b, kv->h_len[b] + steps, kv->max_seq);
+    return PGV_OK;
+}
+
+extern "C" int pgv_llm_decode(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, const int32_t* d_last, float* d_logits, int32_t* d_next, void* stream) {
+    PGV_CHECK(ctx && d_last, "pgv_llm_decode: null argument");
+    PGV_TRY(check_decode(m, kv, 1, "pgv_llm_decode"));
+    hipStream_t s = (hipStream_t)stream;
+    const int B = kv->active;
+    if (d_last != kv->d_cur) PGV_HIP(hipMemcpyAsync(kv->d_cur, d_last, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+    PGV_TRY(decode_step(ctx, m, kv, -1, AM_INC_POS, s));
+    if (d_logits) PGV_HIP(hipMemcpyAsync(d_logits, kv->logits, (size_t)B * m->cfg.vocab * 4, hipMemcpyDeviceToDevice, s));
+    if (d_next) PGV_HIP(hipMemcpyAsync(d_next, kv->d_cur, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
+
+extern "C" int pgv_llm_decode_greedy(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, const int32_t* d_first, int n, int eos_id, int32_t* d_tokens, void* stream) {
+    PGV_CHECK(ctx && d_first && d_tokens, "pgv_llm_decode_greedy: null argument");
+    PGV_CHECK(n >= 1, "pgv_llm_decode_greedy: n must be positive");
+    PGV_TRY(check_decode(m, kv, n, "pgv_llm_decode_greedy"));
+    hipStream_t s = (hipStream_t)stream;
+    const int B = kv->active;
+    if (d_first != kv->d_cur) PGV_HIP(hipMemcpyAsync(kv->d_cur, d_first, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+    PGV_HIP(hipMemsetAsync(kv->d_step, 0, (size_t)kv->B * 4, s));
+    for (int i = 0; i < n; ++i) PGV_TRY(decode_step(ctx, m, kv, eos_id, AM_INC_POS | AM_RECORD, s));
+    PGV_HIP(hipMemcpy2DAsync(d_tokens, (size_t)n * 4, kv->d_hist, (size_t)kv->max_seq * 4, (size_t)n * 4, B, hipMemcpyDeviceToDevice, s));
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// mm_projector
+// ---------------------------------------------------------------------------------------------
 extern "C" int pgv_projector(pgv_ctx* ctx, int dtype, int depth, const void* const* d_weights, const float* const* d_biases, int mm_hidden,
                              int hidden, const void* d_x, int rows, void* d_y, void* stream) {
     PGV_CHECK(ctx && d_weights && d_biases && d_x && d_y, "pgv_projector: null argument");

@@ -1,0 +1,529 @@
+// LLaMA decoder kernels for gfx950 (HF:llama/modeling_llama.py; reference glue video_chatgpt/model/video_chatgpt.py):
+//   embed_splice   : embed_tokens gather + replacement of the <vid_patch> run by projected video rows (:100-168)
+//   rope_kv_write  : rotate-half RoPE on q,k (:129-160) + KV-cache append (prefill)
+//   prefill_attn   : causal flash attention, head_dim 128, K/V streamed from the cache through LDS, MFMA
+//   gemv_mfma      : decode projections y[B,N] = x[B,K] W[N,K]^T for B <= 16 on v_mfma_f32_16x16x32 (HBM-bound:
+//                    every weight byte is read exactly once, split-K across the 8 waves of a workgroup)
+//   decode_attn    : RoPE + cache append + single-query attention over the cache (flash-decoding style)
+//   argmax         : greedy token + per-sequence bookkeeping (position, step, EOS stickiness) on the device
+#include "pgv_common.h"
+
+namespace {
+
+constexpr int HD = 128;   // LLaMA head_dim
+
+// ---------------------------------------------------------------------------------------------
+// embedding gather + video splice -> fp32 residual stream.  row_src[r] >= 0: token id; < 0: -(video row + 1)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void embed_splice_kernel(const int* __restrict__ row_src, const typename T::elem* __restrict__ embed,
+                                                           const typename T::elem* __restrict__ video, float* __restrict__ resid, int H) {
+    const int r = blockIdx.x;
+    const int src = row_src[r];
+    const typename T::elem* p = src >= 0 ? embed + (size_t)src * H : video + (size_t)(-src - 1) * H;
+    for (int c = threadIdx.x * 8; c < H; c += 256 * 8) {
+        const typename T::v8 v = *(const typename T::v8*)(p + c);
+        f32x4_t a, b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] = (float)v[e]; b[e] = (float)v[4 + e]; }
+        *(f32x4_t*)(resid + (size_t)r * H + c) = a;
+        *(f32x4_t*)(resid + (size_t)r * H + c + 4) = b;
+    }
+}
+
+// decode: resid[b] = embed[tok[b]]
+template <typename T>
+__global__ __launch_bounds__(256) void embed_tok_kernel(const int* __restrict__ tok, const typename T::elem* __restrict__ embed,
+                                                        float* __restrict__ resid, int H) {
+    const int b = blockIdx.x;
+    const typename T::elem* p = embed + (size_t)tok[b] * H;
+    for (int c = threadIdx.x * 8; c < H; c += 256 * 8) {
+        const typename T::v8 v = *(const typename T::v8*)(p + c);
+        f32x4_t a, bb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] = (float)v[e]; bb[e] = (float)v[4 + e]; }
+        *(f32x4_t*)(resid + (size_t)b * H + c) = a;
+        *(f32x4_t*)(resid + (size_t)b * H + c + 4) = bb;
+    }
+}
+
+// gather rows (last token of every sequence) of the fp32 residual
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ rows, float* __restrict__ dst, int H) {
+    const int b = blockIdx.x;
+    const f32x4_t* s = (const f32x4_t*)(src + (size_t)rows[b] * H);
+    f32x4_t* d = (f32x4_t*)(dst + (size_t)b * H);
+    for (int c = threadIdx.x; c < H / 4; c += 256) d[c] = s[c];
+}
+
+// ---------------------------------------------------------------------------------------------
+// prefill: RoPE on q (in place in the qkv buffer) and k, append k/v to the cache.
+// rope table: [max_pos][64] (cos, sin) fp32.  One block per token row.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void rope_kv_write_kernel(typename T::elem* __restrict__ qkv, const int* __restrict__ row_b,
+                                                            const int* __restrict__ row_pos, const float2* __restrict__ rope,
+                                                            typename T::elem* __restrict__ Kc, typename T::elem* __restrict__ Vc, int H, int heads, int max_seq) {
+    const int r = blockIdx.x;
+    const int b = row_b[r], pos = row_pos[r];
+    typename T::elem* q = qkv + (size_t)r * 3 * H;
+    typename T::elem* k = q + H;
+    typename T::elem* v = q + 2 * H;
+    for (int idx = threadIdx.x; idx < heads * 64; idx += 256) {
+        const int h = idx >> 6, j = idx & 63;
+        const float2 cs = rope[(size_t)pos * 64 + j];
+        const float q1 = (float)q[h * HD + j], q2 = (float)q[h * HD + j + 64];
+        q[h * HD + j] = T::from_f32(q1 * cs.x - q2 * cs.y);
+        q[h * HD + j + 64] = T::from_f32(q2 * cs.x + q1 * cs.y);
+        const float k1 = (float)k[h * HD + j], k2 = (float)k[h * HD + j + 64];
+        typename T::elem* kd = Kc + (((size_t)b * heads + h) * max_seq + pos) * HD;
+        kd[j] = T::from_f32(k1 * cs.x - k2 * cs.y);
+        kd[j + 64] = T::from_f32(k2 * cs.x + k1 * cs.y);
+        typename T::elem* vd = Vc + (((size_t)b * heads + h) * max_seq + pos) * HD;
+        vd[j] = v[h * HD + j];
+        vd[j + 64] = v[h * HD + j + 64];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// prefill causal attention.  Grid (qtiles, heads, B); 4 waves, wave w owns queries q0 + 32w + (lane&31).
+// Per 64-key chunk: K rows DMA'd into LDS ([64][256 B], 16-B chunks XOR-swizzled by row&15 on the source side),
+// V transposed through registers into V^T [128][144 B] with key bits 2/3 swapped (see vit_attn.hip); then
+// S^T = K Q^T, online softmax (lane-local + one cross-half shuffle), O^T += V^T P^T, all on 32x32x16 MFMA.
+// ---------------------------------------------------------------------------------------------
+struct PrefillAttnArgs {
+    const char* qkv;      // [M, 3H]: rotated q at cols [0,H)
+    char* out;            // [M, H]
+    const char* Kc;       // [B, heads, max_seq, 128]
+    const char* Vc;
+    const int* cu;        // [B+1] row offsets
+    int H, heads, max_seq;
+    float scale_log2e;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void prefill_attn_kernel(PrefillAttnArgs p) {
+    __shared__ __attribute__((aligned(16))) char Ks[64 * 256];
+    __shared__ __attribute__((aligned(16))) char Vt[128 * 144];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int r0 = p.cu[b], S = p.cu[b + 1] - r0;
+    const int q0 = blockIdx.x * 128;
+    if (q0 >= S) return;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int qi = q0 + w * 32 + l31;                 // this lane's query index within the sequence
+    const int qrow = r0 + min(qi, S - 1);
+    const char* kbase = p.Kc + ((size_t)b * p.heads + h) * p.max_seq * HD * 2;
+    const char* vbase = p.Vc + ((size_t)b * p.heads + h) * p.max_seq * HD * 2;
+
+    typename T::v8 qf[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) qf[kk] = *(const typename T::v8*)(p.qkv + ((size_t)qrow * 3 * p.H + h * HD + kk * 16 + hi * 8) * 2);
+
+    f32x16_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[j][e] = 0.f;
+    const float NEG = -1e30f;
+    float mrun = NEG, lrun = 0.f;
+    int koffs[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) koffs[kk] = ((kk * 2 + hi) ^ (l31 & 15)) << 4;
+
+    const int kend = min(S, q0 + 128);
+    for (int kc0 = 0; kc0 < kend; kc0 += 64) {
+        __syncthreads();
+        // stage K: wave-instruction = 4 rows x 256 B
+        {
+            const int srow = lane >> 4, slot = lane & 15;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int g = w * 4 + g4;                  // 16 groups of 4 rows
+                const int row = g * 4 + srow;
+                const int chunk = slot ^ (row & 15);
+                const int kr = min(kc0 + row, S - 1);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + ((size_t)kr * HD + chunk * 8) * 2),
+                                                 (__attribute__((address_space(3))) void*)(Ks + g * 1024), 16, 0, 0);
+            }
+        }
+        // stage V^T
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = tid + it * 256;
+            const int key = idx >> 4, dc = idx & 15;
+            typename T::v8 v;
+            if (kc0 + key < S) v = *(const typename T::v8*)(vbase + ((size_t)(kc0 + key) * HD + dc * 8) * 2);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (typename T::elem)0.0f;
+            }
+            const int pos = (key & ~12) | ((key & 4) << 1) | ((key & 8) >> 1);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) *(typename T::elem*)(Vt + (dc * 8 + e) * 144 + pos * 2) = v[e];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kc0 > q0 + w * 32 + 31) continue;           // chunk entirely in this wave's future: nothing to add
+
+        f32x16_t s[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[c][e] = 0.f;
+            const char* kr = Ks + (c * 32 + l31) * 256;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const typename T::v8 kf = *(const typename T::v8*)(kr + koffs[kk]);
+                s[c] = T::mfma32(kf, qf[kk], s[c]);
+            }
+        }
+        float cmax = NEG;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = kc0 + c * 32 + 4 * hi + (e & 3) + 8 * (e >> 2);
+                float v = s[c][e] * p.scale_log2e;
+                v = (key <= qi && key < S) ? v : NEG;
+                s[c][e] = v;
+                cmax = fmaxf(cmax, v);
+            }
+        cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+        const float mnew = fmaxf(mrun, cmax);
+        const float alpha = exp2f(mrun - mnew);
+        mrun = mnew;
+        float psum = 0.f;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                // a fully masked row (possible only for padded queries) keeps p = exp2(NEG - NEG) = 1; harmless, never stored
+                const float pv = exp2f(s[c][e] - mnew);
+                s[c][e] = pv;
+                psum += pv;
+            }
+        lrun = lrun * alpha + psum;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[j][e] *= alpha;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                typename T::v8 pa;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pa[e] = T::from_f32(s[c][ks * 8 + e]);
+                const int col = (c * 32 + ks * 16 + hi * 8) * 2;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const typename T::v8 vf = *(const typename T::v8*)(Vt + (j * 32 + l31) * 144 + col);
+                    o[j] = T::mfma32(vf, pa, o[j]);
+                }
+            }
+    }
+    const float ltot = lrun + __shfl_xor(lrun, 32, 64);
+    const float inv = 1.0f / ltot;
+    if (qi < S) {
+        char* orow = p.out + ((size_t)(r0 + qi) * p.H + h * HD) * 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = j * 32 + 8 * g + 4 * hi;
+                *(u32x2_t*)(orow + d * 2) = pack4<T>(o[j][g * 4] * inv, o[j][g * 4 + 1] * inv, o[j][g * 4 + 2] * inv, o[j][g * 4 + 3] * inv);
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// decode GEMV on MFMA: y[b, n] = sum_k x[b, k] W[n, k], B <= 16.
+// Workgroup = 8 waves, owns TILES blocks of 16 weight rows; wave w takes k-steps (32 wide) w, w+8, ... so the 8 waves
+// read adjacent 64-B pieces of the same rows.  A operand = W fragment (lane: row l&15, k (l>>4)*8..+8, one 16-B load),
+// B operand = x fragment (lane: batch l&15, same k) served by L2.  Partial 16x16 tiles are reduced through LDS.
+// ---------------------------------------------------------------------------------------------
+enum { GV_STORE16 = 0, GV_RESID = 1, GV_SWIGLU = 2, GV_F32 = 3 };
+
+struct GemvArgs {
+    const char* W; const char* x; char* out;
+    int N, K, B, ldx, ldo;
+};
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(512) void gemv_mfma_kernel(GemvArgs p) {
+    constexpr int TILES = (MODE == GV_SWIGLU) ? 2 : 1;
+    __shared__ f32x4_t red[8][TILES][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kg = lane >> 4;
+    int row[TILES];
+    if constexpr (MODE == GV_SWIGLU) {
+        const int i0 = blockIdx.x * 16;                          // output column block
+        const int base = (i0 >> 5) * 64 + (i0 & 31);
+        row[0] = base + l15;                                     // gate rows
+        row[1] = base + 32 + l15;                                // up rows
+    } else {
+        row[0] = min(blockIdx.x * 16 + l15, p.N - 1);
+    }
+    const char* wp[TILES];
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) wp[t] = p.W + ((size_t)row[t] * p.K + kg * 8) * 2;
+    const char* xp = p.x + ((size_t)min(l15, p.B - 1) * p.ldx + kg * 8) * 2;
+    f32x4_t acc[TILES];
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int nsteps = p.K / 32;
+    constexpr int U = 4;
+    int kk = w;
+    for (; kk + 8 * (U - 1) < nsteps; kk += 8 * U) {
+        typename T::v8 wf[U][TILES], xf[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) wf[u][t] = __builtin_nontemporal_load((const typename T::v8*)(wp[t] + (size_t)(kk + 8 * u) * 64));
+            xf[u] = *(const typename T::v8*)(xp + (size_t)(kk + 8 * u) * 64);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) acc[t] = T::mfma16(wf[u][t], xf[u], acc[t]);
+    }
+    for (; kk < nsteps; kk += 8) {
+        const typename T::v8 xf = *(const typename T::v8*)(xp + (size_t)kk * 64);
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) {
+            const typename T::v8 wf = __builtin_nontemporal_load((const typename T::v8*)(wp[t] + (size_t)kk * 64));
+            acc[t] = T::mfma16(wf, xf, acc[t]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) red[w][t][lane] = acc[t];
+    __syncthreads();
+    if (w != 0) return;
+    f32x4_t tot[TILES];
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+        tot[t] = red[0][t][lane];
+#pragma unroll
+        for (int ww = 1; ww < 8; ++ww) tot[t] += red[ww][t][lane];
+    }
+    // lane holds D[n = kg*4 + r][b = l15]
+    const int b = l15;
+    if (b >= p.B) return;
+    const int n0 = blockIdx.x * 16 + kg * 4;
+    if constexpr (MODE == GV_SWIGLU) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float g = tot[0][r]; v[r] = g / (1.0f + __expf(-g)) * tot[1][r]; }
+        *(u32x2_t*)(p.out + ((size_t)b * p.ldo + n0) * 2) = pack4<T>(v[0], v[1], v[2], v[3]);
+    } else if constexpr (MODE == GV_STORE16) {
+        *(u32x2_t*)(p.out + ((size_t)b * p.ldo + n0) * 2) = pack4<T>(tot[0][0], tot[0][1], tot[0][2], tot[0][3]);
+    } else if constexpr (MODE == GV_RESID) {
+        f32x4_t* rp = (f32x4_t*)(p.out + ((size_t)b * p.ldo + n0) * 4);
+        *rp = *rp + tot[0];
+    } else {
+        float* op = (float*)p.out + (size_t)b * p.ldo + n0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (n0 + r < p.N) op[r] = tot[0][r];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// decode attention: one workgroup per (sequence, head); 4 waves; lane = (key slot 0..3, 16-B d chunk 0..15).
+// Applies RoPE to the fresh q/k, appends k/v to the cache at pos[b], attends over keys [0, pos].
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void decode_attn_kernel(const typename T::elem* __restrict__ qkv, const int* __restrict__ pos_arr,
+                                                          const float2* __restrict__ rope, typename T::elem* __restrict__ Kc,
+                                                          typename T::elem* __restrict__ Vc, typename T::elem* __restrict__ out, int H, int heads,
+                                                          int max_seq, float scale_log2e) {
+    __shared__ float qs[HD];
+    __shared__ __attribute__((aligned(16))) typename T::elem ks[HD];
+    __shared__ __attribute__((aligned(16))) typename T::elem vs[HD];
+    __shared__ float st_m[16], st_l[16];
+    __shared__ float st_o[16][HD];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int h = blockIdx.x, b = blockIdx.y;
+    const int pos = pos_arr[b];
+    const typename T::elem* q = qkv + (size_t)b * 3 * H + h * HD;
+    const typename T::elem* k = q + H;
+    const typename T::elem* v = q + 2 * H;
+    typename T::elem* kcache = Kc + ((size_t)b * heads + h) * max_seq * HD;
+    typename T::elem* vcache = Vc + ((size_t)b * heads + h) * max_seq * HD;
+    if (tid < 64) {
+        const float2 cs = rope[(size_t)pos * 64 + tid];
+        const float q1 = (float)q[tid], q2 = (float)q[tid + 64];
+        qs[tid] = (float)T::from_f32(q1 * cs.x - q2 * cs.y);          // rounded to the activation dtype like the prefill path
+        qs[tid + 64] = (float)T::from_f32(q2 * cs.x + q1 * cs.y);
+    } else if (tid < 128) {
+        const int j = tid - 64;
+        const float2 cs = rope[(size_t)pos * 64 + j];
+        const float k1 = (float)k[j], k2 = (float)k[j + 64];
+        const typename T::elem a = T::from_f32(k1 * cs.x - k2 * cs.y), c = T::from_f32(k2 * cs.x + k1 * cs.y);
+        ks[j] = a; ks[j + 64] = c;
+        kcache[(size_t)pos * HD + j] = a; kcache[(size_t)pos * HD + j + 64] = c;
+    } else {
+        const int j = tid - 128;
+        const typename T::elem a = v[j];
+        vs[j] = a;
+        vcache[(size_t)pos * HD + j] = a;
+    }
+    __syncthreads();
+    const int slot = lane >> 4, dc = lane & 15;
+    float qr[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qr[e] = qs[dc * 8 + e] * scale_log2e;
+    float m = -1e30f, l = 0.f, o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int key = w * 4 + slot; key <= pos; key += 16) {
+        typename T::v8 kv8, vv8;
+        if (key == pos) { kv8 = *(const typename T::v8*)(ks + dc * 8); vv8 = *(const typename T::v8*)(vs + dc * 8); }
+        else { kv8 = *(const typename T::v8*)(kcache + (size_t)key * HD + dc * 8); vv8 = *(const typename T::v8*)(vcache + (size_t)key * HD + dc * 8); }
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += qr[e] * (float)kv8[e];
+        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+        const float mn = fmaxf(m, s);
+        const float alpha = exp2f(m - mn), pv = exp2f(s - mn);
+        m = mn;
+        l = l * alpha + pv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = o[e] * alpha + pv * (float)vv8[e];
+    }
+    const int sid = w * 4 + slot;
+    if (dc == 0) { st_m[sid] = m; st_l[sid] = l; }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) st_o[sid][dc * 8 + e] = o[e];
+    __syncthreads();
+    if (tid < HD) {
+        float M = -1e30f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) M = fmaxf(M, st_m[i]);
+        float L = 0.f, acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float f = exp2f(st_m[i] - M);
+            L += st_l[i] * f;
+            acc += st_o[i][tid] * f;
+        }
+        out[(size_t)b * H + h * HD + tid] = T::from_f32(acc / L);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// greedy argmax over fp32 logits (first index wins ties, like torch.argmax on CPU) + bookkeeping.
+// advance != 0: also pos[b]++, hist[b][step[b]++] = token, EOS stickiness.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ logits, int V, int* __restrict__ next, int* __restrict__ pos,
+                                                      int* __restrict__ step, int* __restrict__ hist, int hist_stride, int* __restrict__ done,
+                                                      int eos, int advance) {
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* lg = logits + (size_t)b * V;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < V; i += 1024) {
+        const float v = lg[i];
+        if (v > best) { best = v; bi = i; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if ((tid & 63) == 0) { sv[tid >> 6] = best; si[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int i = 1; i < 16; ++i)
+            if (sv[i] > best || (sv[i] == best && si[i] < bi)) { best = sv[i]; bi = si[i]; }
+        int tok = bi;
+        if (advance) {
+            if (done[b]) tok = eos;
+            else if (eos >= 0 && tok == eos) done[b] = 1;
+            hist[(size_t)b * hist_stride + step[b]] = tok;
+            step[b] += 1;
+            pos[b] += 1;
+        }
+        next[b] = tok;
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+int pgv_launch_embed_splice(int dtype, const int* row_src, const void* embed, const void* video, float* resid, int M, int H, hipStream_t s) {
+    PGV_CHECK(H % 8 == 0, "embed: hidden must be a multiple of 8");
+    PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((embed_splice_kernel<T>), dim3(M), dim3(256), 0, s, row_src, (const typename T::elem*)embed,
+                                                    (const typename T::elem*)video, resid, H));
+    return PGV_OK;
+}
+int pgv_launch_embed_tok(int dtype, const int* tok, const void* embed, float* resid, int B, int H, hipStream_t s) {
+    PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((embed_tok_kernel<T>), dim3(B), dim3(256), 0, s, tok, (const typename T::elem*)embed, resid, H));
+    return PGV_OK;
+}
+int pgv_launch_gather_rows(const float* src, const int* rows, float* dst, int B, int H, hipStream_t s) {
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(B), dim3(256), 0, s, src, rows, dst, H);
+    return PGV_OK;
+}
+int pgv_launch_rope_kv_write(int dtype, void* qkv, const int* row_b, const int* row_pos, const void* rope, void* Kc, void* Vc, int M, int H,
+                             int heads, int max_seq, hipStream_t s) {
+    PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((rope_kv_write_kernel<T>), dim3(M), dim3(256), 0, s, (typename T::elem*)qkv, row_b, row_pos,
+                                                    (const float2*)rope, (typename T::elem*)Kc, (typename T::elem*)Vc, H, heads, max_seq));
+    return PGV_OK;
+}
+int pgv_launch_prefill_attn(pgv_ctx* ctx, int dtype, const void* qkv, void* out, const void* Kc, const void* Vc, const int* cu, int B, int max_len,
+                            int H, int heads, int max_seq, double flops, hipStream_t s) {
+    PrefillAttnArgs a;
+    a.qkv = (const char*)qkv; a.out = (char*)out; a.Kc = (const char*)Kc; a.Vc = (const char*)Vc; a.cu = cu;
+    a.H = H; a.heads = heads; a.max_seq = max_seq;
+    a.scale_log2e = 0.08838834764831845f * 1.4426950408889634f;    // 128^-0.5 * log2(e)
+    dim3 grid((max_len + 127) / 128, heads, B);
+    pgv_prof_begin(ctx, 2, s);
+    PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((prefill_attn_kernel<T>), grid, dim3(256), 0, s, a));
+    pgv_prof_end(ctx, 2, s, flops, 0.0);
+    return PGV_OK;
+}
+
+int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void* x, int ldx, void* out, int ldo, int N, int K, int B, hipStream_t s) {
+    PGV_CHECK(B >= 1 && B <= 16, "gemv: batch %d outside [1,16]", B);
+    PGV_CHECK(K % 32 == 0, "gemv: K=%d must be a multiple of 32", K);
+    GemvArgs a;
+    a.W = (const char*)W; a.x = (const char*)x; a.out = (char*)out; a.N = N; a.K = K; a.B = B; a.ldx = ldx; a.ldo = ldo;
+    int grid;
+    if (mode == GV_SWIGLU) { PGV_CHECK(N % 64 == 0, "gemv swiglu: N=%d must be a multiple of 64", N); grid = N / 32; }
+    else { if (mode != GV_F32) PGV_CHECK(N % 16 == 0, "gemv: N=%d must be a multiple of 16", N); grid = (N + 15) / 16; }
+    pgv_prof_begin(ctx, 3, s);
+#define PGV_GEMV(MODE_) PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gemv_mfma_kernel<T, MODE_>), dim3(grid), dim3(512), 0, s, a))
+    switch (mode) {
+        case GV_STORE16: PGV_GEMV(GV_STORE16); break;
+        case GV_RESID: PGV_GEMV(GV_RESID); break;
+        case GV_SWIGLU: PGV_GEMV(GV_SWIGLU); break;
+        case GV_F32: PGV_GEMV(GV_F32); break;
+        default: pgv_set_error("gemv: bad mode %d", mode); return PGV_EINVAL;
+    }
+#undef PGV_GEMV
+    pgv_prof_end(ctx, 3, s, 2.0 * B * (double)N * K, 2.0 * (double)N * K);
+    return PGV_OK;
+}
+
+int pgv_launch_decode_attn(pgv_ctx* ctx, int dtype, const void* qkv, const int* pos, const void* rope, void* Kc, void* Vc, void* out, int B, int H,
+                           int heads, int max_seq, double bytes, hipStream_t s) {
+    const float sc = 0.08838834764831845f * 1.4426950408889634f;
+    pgv_prof_begin(ctx, 4, s);
+    PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((decode_attn_kernel<T>), dim3(heads, B), dim3(256), 0, s, (const typename T::elem*)qkv, pos,
+                                                    (const float2*)rope, (typename T::elem*)Kc, (typename T::elem*)Vc, (typename T::elem*)out, H, heads,
+                                                    max_seq, sc));
+    pgv_prof_end(ctx, 4, s, 0.0, bytes);
+    return PGV_OK;
+}
+
+int pgv_launch_argmax(const float* logits, int V, int B, int* next, int* pos, int* step, int* hist, int hist_stride, int* done, int eos, int advance,
+                      hipStream_t s) {
+    hipLaunchKernelGGL(argmax_kernel, dim3(B), dim3(1024), 0, s, logits, V, next, pos, step, hist, hist_stride, done, eos, advance);
+    return PGV_OK;
+}

@@ -1,0 +1,395 @@
+"""`VideoChatGPTLlamaForCausalLM` drop-in: the object `initialize_model` returns in slot 1 and
+`video_chatgpt_infer` drives through `model.get_model().vision_config`, `model.get_model().mm_projector` and
+`model.generate(input_ids, video_spatio_temporal_features=..., do_sample, temperature, max_new_tokens,
+stopping_criteria)` (reference: video_chatgpt/model/video_chatgpt.py:16-325; call sites
+video_chatgpt/inference.py:67,105-112, chat.py:148-154, eval/model_utils.py:104-144).
+
+The decoder stack, the video splice, lm_head and greedy picking run in libpgv (hand-written gfx950 kernels);
+this file is host orchestration only: placeholder validation (same ValueErrors as the reference), the
+token loop, stopping criteria and sampling glue.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from ..constants import CLIP_WIDTH
+from .multimodal_projector.builder import HipLinear, IdentityMap, build_vision_projector
+
+DEFAULT_VIDEO_TOKEN = "<video>"
+DEFAULT_VIDEO_PATCH_TOKEN = "<vid_patch>"
+DEFAULT_VID_START_TOKEN = "<vid_start>"
+DEFAULT_VID_END_TOKEN = "<vid_end>"
+
+
+class VisionConfig:
+    """Same fields as the reference's VisionConfig (model/video_chatgpt.py:16-30)."""
+
+    def __init__(self, frame_size=224, patch_size=14, hidden_size=1024):
+        self.frame_size = frame_size
+        self.patch_size = patch_size
+        self.hidden_size = hidden_size
+        self.use_vid_start_end = None
+        self.vid_start_token = None
+        self.vid_end_token = None
+        self.vid_patch_token = None
+
+
+class VideoChatGPTConfig:
+    """The LlamaConfig fields the path reads + the multimodal keys of config.json
+    (`mm_vision_tower`, `use_mm_proj`, `mm_hidden_size`, `mm_projector_type`; model/video_chatgpt.py:43-55)."""
+    model_type = "VideoChatGPT"
+
+    def __init__(self, vocab_size=32000, hidden_size=4096, intermediate_size=11008, num_hidden_layers=32,
+                 num_attention_heads=32, num_key_value_heads=None, max_position_embeddings=4096, rms_norm_eps=1e-5,
+                 rope_theta=10000.0, mm_vision_tower=None, use_mm_proj=True, mm_hidden_size=1024,
+                 mm_projector_type="linear", eos_token_id=2, bos_token_id=1, pad_token_id=None, **extra):
+        if num_key_value_heads not in (None, num_attention_heads):
+            raise ValueError("grouped-query checkpoints are outside the PG-Video-LLaVA path (7B/13B are MHA)")
+        self.vocab_size, self.hidden_size, self.intermediate_size = vocab_size, hidden_size, intermediate_size
+        self.num_hidden_layers, self.num_attention_heads = num_hidden_layers, num_attention_heads
+        self.max_position_embeddings, self.rms_norm_eps, self.rope_theta = max_position_embeddings, rms_norm_eps, rope_theta
+        self.mm_vision_tower, self.use_mm_proj, self.mm_hidden_size = mm_vision_tower, use_mm_proj, mm_hidden_size
+        self.mm_projector_type = mm_projector_type
+        self.eos_token_id, self.bos_token_id, self.pad_token_id = eos_token_id, bos_token_id, pad_token_id
+        self.extra = extra
+
+    @classmethod
+    def from_pretrained(cls, path: str) -> "VideoChatGPTConfig":
+        with open(os.path.join(path, "config.json")) as f:
+            return cls(**json.load(f))
+
+
+class VideoChatGPTLlamaModel(nn.Module):
+    """`model.get_model()`: carries vision_config and mm_projector like the reference's inner LlamaModel subclass."""
+
+    def __init__(self, config: VideoChatGPTConfig, vision_config: VisionConfig, dtype, device):
+        super().__init__()
+        self.config = config
+        self.vision_config = vision_config
+        if config.use_mm_proj:
+            if vision_config.frame_size == 224:      # LLaVA-Lightning style bare Linear (model/video_chatgpt.py:52-53)
+                self.mm_projector = HipLinear(config.mm_hidden_size, config.hidden_size, dtype, device)
+            else:                                     # LLaVA-1.5: by config.mm_projector_type (:54-55)
+                self.mm_projector = build_vision_projector(config, dtype=dtype, device=device)
+
+
+class VideoChatGPTLlamaForCausalLM(nn.Module):
+    def __init__(self, config: VideoChatGPTConfig, vision_config: Optional[VisionConfig] = None,
+                 torch_dtype: torch.dtype = torch.float16, device=None):
+        super().__init__()
+        self.config = config
+        self.dtype_ = torch_dtype
+        self.ctx = _lib.Context.get(device)
+        self.device_ = torch.device("cuda", self.ctx.device)
+        if vision_config is None:
+            vision_config = _vision_config_from(config.mm_vision_tower)
+        if vision_config.hidden_size != CLIP_WIDTH:
+            raise ValueError(f"CLIP width must be {CLIP_WIDTH} (the reference hard-codes it at model/video_chatgpt.py:106)")
+        self.model = VideoChatGPTLlamaModel(config, vision_config, torch_dtype, self.device_)
+        lc = _lib.LlmConfig(config.vocab_size, config.hidden_size, config.intermediate_size, config.num_hidden_layers,
+                            config.num_attention_heads, config.rms_norm_eps, config.rope_theta)
+        h = C.c_void_p()
+        _lib.check(self.ctx.lib.pgv_llm_create(self.ctx.handle, C.byref(lc), _lib.dtype_code(torch_dtype), C.byref(h)), "pgv_llm_create")
+        self.handle = h
+        self._kv: dict = {}
+
+    def __del__(self):
+        try:
+            for kv in getattr(self, "_kv", {}).values():
+                self.ctx.lib.pgv_kv_destroy(kv)
+            if getattr(self, "handle", None):
+                self.ctx.lib.pgv_llm_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    # ---- HF-module surface the reference touches ----------------------------------------------------
+    def get_model(self) -> VideoChatGPTLlamaModel:
+        return self.model
+
+    def eval(self):
+        return self
+
+    def cuda(self, *a, **k):
+        return self
+
+    def half(self):
+        return self
+
+    @property
+    def device(self):
+        return self.device_
+
+    @property
+    def vocab_size(self) -> int:
+        return self.ctx.lib.pgv_llm_vocab(self.handle)
+
+    def resize_token_embeddings(self, new_num_tokens: int):
+        """eval/model_utils.py:119: grow embed_tokens / lm_head for the three video tokens."""
+        _lib.check(self.ctx.lib.pgv_llm_resize_vocab(self.handle, int(new_num_tokens), _lib.stream_ptr(self.device_)),
+                   "resize_token_embeddings")
+        self.config.vocab_size = int(new_num_tokens)
+
+    # ---- weights ----------------------------------------------------------------------------------------
+    def load_state_dict(self, sd: dict, strict: bool = True):
+        """Routes `model.mm_projector.*` to the projector module and every other key to the packed device weights.
+        Returns an object with `.missing_keys` / `.unexpected_keys` like torch (eval/model_utils.py:124-126)."""
+        lib = self.ctx.lib
+        unexpected: List[str] = []
+        proj_sd = {}
+        for k, v in sd.items():
+            if isinstance(v, np.ndarray):
+                v = torch.from_numpy(v)
+            if k.startswith("model.mm_projector."):
+                proj_sd[k[len("model.mm_projector."):]] = v
+                continue
+            if "rotary_emb.inv_freq" in k:
+                continue
+            v = v.detach()
+            if v.dtype not in (torch.float32, torch.float16, torch.bfloat16):
+                v = v.float()
+            v = v.contiguous()
+            if v.is_cuda:
+                torch.cuda.current_stream(v.device).synchronize()
+            dev = 1 if v.is_cuda else 0
+            if k in ("model.embed_tokens.weight", "lm_head.weight"):
+                rows = min(v.shape[0], self.vocab_size)      # a checkpoint with a smaller vocabulary fills the first rows
+                rc = lib.pgv_llm_load_rows(self.handle, k.encode(), v.data_ptr(), _lib.dtype_code(v.dtype), dev, 0, rows,
+                                           _lib.stream_ptr(self.device_))
+            else:
+                rc = lib.pgv_llm_load_tensor(self.handle, k.encode(), v.data_ptr(), _lib.dtype_code(v.dtype), dev,
+                                             _lib.stream_ptr(self.device_))
+            if rc == _lib.PGV_ENAME:
+                unexpected.append(k)
+                continue
+            _lib.check(rc, f"load {k}")
+        if proj_sd:
+            mp = self.model.mm_projector
+            res = mp.load_state_dict({k: v.to(self.dtype_) for k, v in proj_sd.items()}, strict=False)
+            unexpected += ["model.mm_projector." + k for k in res.unexpected_keys]
+        torch.cuda.synchronize(self.device_)
+        missing = lib.pgv_llm_missing(self.handle)
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"load_state_dict: {missing} decoder tensors missing, unexpected keys {unexpected}")
+
+        class _Status:
+            pass
+        st = _Status()
+        st.missing_keys = [f"<{missing} decoder tensors>"] if missing else []
+        st.unexpected_keys = unexpected
+        return st
+
+    @classmethod
+    def from_pretrained(cls, path: str, low_cpu_mem_usage: bool = True, torch_dtype: torch.dtype = torch.float16,
+                        use_cache: bool = True, device=None, vision_config: Optional[VisionConfig] = None):
+        """Load a local HF checkpoint directory (config.json + *.safetensors or pytorch_model*.bin shards)."""
+        cfg = VideoChatGPTConfig.from_pretrained(path)
+        model = cls(cfg, vision_config, torch_dtype, device)
+        files = sorted(f for f in os.listdir(path) if f.endswith(".safetensors"))
+        if files:
+            from safetensors.torch import load_file
+            for f in files:
+                model.load_state_dict(load_file(os.path.join(path, f)), strict=False)
+        else:
+            for f in sorted(f for f in os.listdir(path) if f.startswith("pytorch_model") and f.endswith(".bin")):
+                model.load_state_dict(torch.load(os.path.join(path, f), map_location="cpu"), strict=False)
+        if model.ctx.lib.pgv_llm_missing(model.handle):
+            raise RuntimeError(f"{path}: decoder checkpoint is incomplete")
+        return model
+
+    # ---- prompt validation (host): same checks and messages as model/video_chatgpt.py:113-128,150-157 ----
+    def _video_positions(self, seqs: Sequence[Sequence[int]], num_video_rows: int) -> List[int]:
+        vc = self.model.vision_config
+        out = []
+        for ids in seqs:
+            a = np.asarray(ids)
+            if int((a == vc.vid_patch_token).sum()) == 0:
+                out.append(-1)                          # text-only sample (:113-118)
+                continue
+            if vc.use_vid_start_end:
+                starts = np.nonzero(a == vc.vid_start_token)[0]
+                if len(starts) != int((a == vc.vid_end_token).sum()):
+                    raise ValueError("The number of video start tokens and video end tokens should be the same.")
+                pos = -1
+                for p in starts.tolist():
+                    if p + num_video_rows + 1 >= len(a) or a[p + num_video_rows + 1] != vc.vid_end_token:
+                        raise ValueError("The video end token should follow the video start token.")
+                    pos = p                              # with several runs the reference keeps the last splice (:123-146)
+                out.append(pos)
+            else:
+                idx = np.nonzero(a == vc.vid_patch_token)[0]
+                if len(idx) != num_video_rows:
+                    raise ValueError("The number of video patch tokens should be the same as the number of video patches.")
+                if (idx != np.arange(idx[0], idx[0] + num_video_rows)).any():
+                    raise ValueError("The video patch tokens should be consecutive.")
+                out.append(int(idx[0]) - 1)              # rows (pos, pos+V] are replaced
+        return out
+
+    # ---- KV cache handles --------------------------------------------------------------------------------
+    def _get_kv(self, batch: int, max_seq: int):
+        key = (batch, max_seq)
+        if key not in self._kv:
+            for old in self._kv.values():               # keep one cache alive (they are GBs)
+                self.ctx.lib.pgv_kv_destroy(old)
+            self._kv.clear()
+            h = C.c_void_p()
+            _lib.check(self.ctx.lib.pgv_kv_create(self.ctx.handle, self.handle, batch, max_seq, C.byref(h)), "pgv_kv_create")
+            self._kv[key] = h
+        return self._kv[key]
+
+    # ---- low-level steps (used by generate and by the parity tests) -------------------------------------
+    def prefill(self, seqs: Sequence[Sequence[int]], video_spatio_temporal_features: Optional[torch.Tensor], max_seq: int,
+                want_logits: bool = False):
+        """Run the prompt(s); returns (kv handle, next-token ids [B] int32 on device, logits [B, vocab] or None)."""
+        B = len(seqs)
+        lens = [len(s) for s in seqs]
+        feats = video_spatio_temporal_features
+        proj = None
+        V = 0
+        vid_pos = [-1] * B
+        if feats is not None and not (max(lens) == 1):     # the reference skips the splice when input_ids.shape[1]==1 (:103)
+            if feats.dim() == 2:
+                feats = feats.unsqueeze(0)
+            proj = self.model.mm_projector(feats.to(self.device_))         # [B, V, hidden]  (:105)
+            if isinstance(self.model.mm_projector, IdentityMap):
+                proj = proj.to(self.dtype_)
+            proj = proj.contiguous()
+            V = proj.shape[1]
+            if proj.shape[0] != B:
+                raise ValueError(f"{proj.shape[0]} video feature sets for {B} prompts")
+            vid_pos = self._video_positions(seqs, V)
+        kv = self._get_kv(max(B, 1), max_seq)
+        flat = np.concatenate([np.asarray(s, dtype=np.int32) for s in seqs])
+        h_lens = (C.c_int32 * B)(*lens)
+        h_pos = (C.c_int32 * B)(*vid_pos)
+        nxt = torch.empty(B, dtype=torch.int32, device=self.device_)
+        logits = torch.empty(B, self.vocab_size, dtype=torch.float32, device=self.device_) if want_logits else None
+        _lib.check(self.ctx.lib.pgv_llm_prefill(self.ctx.handle, self.handle, kv, flat.ctypes.data_as(C.c_void_p), h_lens, B,
+                                                proj.data_ptr() if proj is not None else None, V, h_pos,
+                                                logits.data_ptr() if logits is not None else None, nxt.data_ptr(),
+                                                _lib.stream_ptr(self.device_)), "pgv_llm_prefill")
+        return kv, nxt, logits
+
+    def decode_step(self, kv, last: torch.Tensor, want_logits: bool = False):
+        B = last.shape[0]
+        nxt = torch.empty(B, dtype=torch.int32, device=self.device_)
+        logits = torch.empty(B, self.vocab_size, dtype=torch.float32, device=self.device_) if want_logits else None
+        _lib.check(self.ctx.lib.pgv_llm_decode(self.ctx.handle, self.handle, kv, last.data_ptr(),
+                                               logits.data_ptr() if logits is not None else None, nxt.data_ptr(),
+                                               _lib.stream_ptr(self.device_)), "pgv_llm_decode")
+        return nxt, logits
+
+    def decode_greedy(self, kv, first: torch.Tensor, n: int, eos_id: int = -1) -> torch.Tensor:
+        B = first.shape[0]
+        toks = torch.empty(B, n, dtype=torch.int32, device=self.device_)
+        _lib.check(self.ctx.lib.pgv_llm_decode_greedy(self.ctx.handle, self.handle, kv, first.data_ptr(), n, eos_id, toks.data_ptr(),
+                                                      _lib.stream_ptr(self.device_)), "pgv_llm_decode_greedy")
+        return toks
+
+    # ---- generate ---------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def generate(self, input_ids, video_spatio_temporal_features: Optional[torch.Tensor] = None, do_sample: bool = False,
+                 temperature: float = 1.0, max_new_tokens: int = 1024, stopping_criteria=None, eos_token_id="config",
+                 chunk: int = 32, generator: Optional[torch.Generator] = None, **_unused):
+        """Returns LongTensor [B, S + n_new] on the device, prompt echoed (checked by inference.py:115-117).
+
+        input_ids: LongTensor [B, S] (equal-length prompts, the reference's case) or a list of id lists (ragged batch).
+        Greedy without stopping criteria runs `chunk` steps per host round trip; sampling (the reference's default
+        temperature-0.2 multinomial, inference.py:109-110) and stopping criteria need the token on the host each step."""
+        if torch.is_tensor(input_ids):
+            seqs = [row.tolist() for row in input_ids.cpu()]
+        else:
+            seqs = [list(s) for s in input_ids]
+        B = len(seqs)
+        eos = self.config.eos_token_id if eos_token_id == "config" else eos_token_id
+        eos_i = -1 if eos is None else int(eos)
+        max_seq = max(len(s) for s in seqs) + max_new_tokens
+        if max_seq > self.config.max_position_embeddings:
+            raise ValueError(f"prompt + max_new_tokens = {max_seq} exceeds max_position_embeddings {self.config.max_position_embeddings}")
+        max_seq = (max_seq + 63) // 64 * 64
+        criteria = list(stopping_criteria) if stopping_criteria else []
+        stepwise = bool(criteria) or do_sample
+
+        def pick(logits):
+            if not do_sample:
+                return logits.argmax(-1).to(torch.int32)
+            probs = torch.softmax(logits / max(float(temperature), 1e-6), dim=-1)
+            return torch.multinomial(probs, 1, generator=generator).squeeze(1).to(torch.int32)
+
+        kv, nxt, logits = self.prefill(seqs, video_spatio_temporal_features, max_seq, want_logits=do_sample)
+        if do_sample:
+            nxt = pick(logits)
+        new = [[] for _ in range(B)]
+        done = [False] * B
+        prompt_t = [torch.tensor(s, dtype=torch.long) for s in seqs]
+
+        def absorb(tok_host) -> bool:
+            for b in range(B):
+                if not done[b]:
+                    new[b].append(int(tok_host[b]))
+                    if eos_i >= 0 and int(tok_host[b]) == eos_i:
+                        done[b] = True
+            if all(done):
+                return True
+            if criteria and B == 1:
+                cur = torch.cat([prompt_t[0], torch.tensor(new[0], dtype=torch.long)])[None]
+                if any(c(cur, None) for c in criteria):
+                    return True
+            return False
+
+        if max_new_tokens >= 1:
+            if criteria and B == 1:                       # HF calls the criteria once before the first new token is appended
+                for c in criteria:
+                    c(prompt_t[0][None], None)
+            stop = absorb(nxt.cpu())
+            n_gen = 1
+            while not stop and n_gen < max_new_tokens:
+                if stepwise:
+                    nxt, logits = self.decode_step(kv, nxt, want_logits=do_sample)
+                    if do_sample:
+                        nxt = pick(logits)
+                    stop = absorb(nxt.cpu())
+                    n_gen += 1
+                else:
+                    n = min(chunk, max_new_tokens - n_gen)
+                    toks = self.decode_greedy(kv, nxt, n, eos_i)
+                    host = toks.cpu()
+                    for i in range(n):
+                        stop = absorb(host[:, i])
+                        n_gen += 1
+                        if stop:
+                            break
+                    nxt = toks[:, n - 1].contiguous()
+        width = max(len(s) + len(n_) for s, n_ in zip(seqs, new))
+        pad = eos_i if eos_i >= 0 else 0
+        out = torch.full((B, width), pad, dtype=torch.long)
+        for b in range(B):
+            row = seqs[b] + new[b]
+            out[b, :len(row)] = torch.tensor(row, dtype=torch.long)
+        return out.to(self.device_)
+
+
+def _vision_config_from(mm_vision_tower) -> VisionConfig:
+    """VisionConfig from the CLIP config the checkpoint names (model/video_chatgpt.py:43-49).  Accepts a local
+    directory with a CLIP config.json, a CLIPVisionTowerConfig-like object, or the two published hub names."""
+    if mm_vision_tower is None:
+        return VisionConfig()
+    if hasattr(mm_vision_tower, "image_size"):
+        c = mm_vision_tower
+        return VisionConfig(frame_size=c.image_size, patch_size=c.patch_size, hidden_size=c.hidden_size)
+    if isinstance(mm_vision_tower, str) and os.path.isdir(mm_vision_tower):
+        from ..vision_tower import CLIPVisionTowerConfig
+        c = CLIPVisionTowerConfig.from_pretrained(mm_vision_tower)
+        return VisionConfig(frame_size=c.image_size, patch_size=c.patch_size, hidden_size=c.hidden_size)
+    known = {"openai/clip-vit-large-patch14": 224, "openai/clip-vit-large-patch14-336": 336}
+    if mm_vision_tower in known:
+        return VisionConfig(frame_size=known[mm_vision_tower], patch_size=14, hidden_size=1024)
+    raise ValueError(f"cannot resolve mm_vision_tower={mm_vision_tower!r} offline: pass a local CLIP directory")
