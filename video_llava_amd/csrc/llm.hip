@@ -2,6 +2,7 @@
 // Replaces VideoChatGPTLlamaForCausalLM.forward (video_chatgpt/model/video_chatgpt.py:193-251 -> :82-175 -> HF LlamaModel)
 // as driven by model.generate (video_chatgpt/inference.py:105-112).
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "pgv_common.h"
@@ -57,6 +58,11 @@ struct pgv_kv {
     std::vector<int> h_len;
     std::vector<int> h_meta;           // staging for prefill row maps (kept alive across the async copy)
     int active = 0;                     // sequences of the last prefill
+    // one decode step captured as a hipGraph (all kernel arguments are fixed device addresses; positions, current
+    // tokens and step counters live in device memory and are advanced by the argmax kernel)
+    hipGraphExec_t gexec = nullptr;
+    int g_B = 0, g_eos = 0, g_flags = 0;
+    bool warmed = false;
 };
 
 extern "C" int pgv_llm_create(pgv_ctx* ctx, const pgv_llm_config* cfg, int dtype, pgv_llm** out) {
@@ -209,6 +215,7 @@ extern "C" int pgv_kv_create(pgv_ctx* ctx, pgv_llm* llm, int batch, int max_seq,
 
 extern "C" void pgv_kv_destroy(pgv_kv* kv) {
     if (!kv) return;
+    if (kv->gexec) (void)hipGraphExecDestroy(kv->gexec);
     if (kv->blob) (void)hipFree(kv->blob);
     delete kv;
 }
@@ -312,7 +319,7 @@ extern "C" int pgv_llm_prefill(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, const int32
 // ---------------------------------------------------------------------------------------------
 // decode
 // ---------------------------------------------------------------------------------------------
-static int decode_step(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int eos, int flags, hipStream_t s) {
+static int decode_enqueue(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int eos, int flags, hipStream_t s) {
     const int H = m->cfg.hidden, I = m->cfg.inter, heads = m->cfg.heads, B = kv->active;
     PGV_TRY(pgv_launch_embed_tok(m->dtype, kv->d_cur, m->embed, kv->resid, B, H, s));
     double kv_bytes = 0;
@@ -328,6 +335,38 @@ static int decode_step(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int eos, int flags,
         PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_RESID, l.wdown, kv->act, I, kv->resid, H, H, I, B, s));
     }
     PGV_TRY(lm_head_and_pick(ctx, m, kv, B, eos, flags, s));
+    return PGV_OK;
+}
+
+static bool graphs_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("PGV_NO_GRAPH"); v = (e && e[0] == '1') ? 0 : 1; }
+    return v == 1;
+}
+
+// One decode step: eager the first time (loads code objects), then replayed from a captured hipGraph.  Per-family
+// event timers need eager launches, so profiling disables the graph.
+static int decode_step(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int eos, int flags, hipStream_t s) {
+    const int B = kv->active;
+    if (ctx->prof || !graphs_enabled() || !kv->warmed) {
+        kv->warmed = true;
+        PGV_TRY(decode_enqueue(ctx, m, kv, eos, flags, s));
+    } else {
+        if (!kv->gexec || kv->g_B != B || kv->g_eos != eos || kv->g_flags != flags) {
+            if (kv->gexec) { (void)hipGraphExecDestroy(kv->gexec); kv->gexec = nullptr; }
+            hipGraph_t graph = nullptr;
+            PGV_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
+            const int rc = decode_enqueue(ctx, m, kv, eos, flags, s);
+            hipError_t e = hipStreamEndCapture(s, &graph);
+            if (rc != PGV_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+            if (e != hipSuccess) { pgv_set_error("decode graph capture failed: %s", hipGetErrorString(e)); return PGV_EHIP; }
+            e = hipGraphInstantiate(&kv->gexec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (e != hipSuccess) { kv->gexec = nullptr; pgv_set_error("decode graph instantiate failed: %s", hipGetErrorString(e)); return PGV_EHIP; }
+            kv->g_B = B; kv->g_eos = eos; kv->g_flags = flags;
+        }
+        PGV_HIP(hipGraphLaunch(kv->gexec, s));
+    }
     for (int b = 0; b < B; ++b) kv->h_len[b] += 1;
     return PGV_OK;
 }

@@ -1,0 +1,90 @@
+"""Data-parallel video QA over the GPUs of one node: one process per GPU, clips sharded by index, every rank holds a
+full replica of tower + projector + decoder, and the ONLY collective on the path is the final answer collation
+(one all-gather of a fixed-shape int32 token buffer + lengths; RCCL over xGMI with backend "nccl", gloo on CPU).
+
+Replaces the serial `for sample in tqdm(gt_questions)` loops of the reference's eval runners
+(video_chatgpt/eval/run_inference_qa_activitynet.py:63-104 and siblings): clips are independent, so the shard loop
+needs no data-path communication.  A clip that fails keeps its slot with length 0 (the reference prints and
+continues, :103-104), so the gather shape never depends on failures.
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, List, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend: str | None = None) -> tuple[int, int, int]:
+    """(rank, world, local_rank) from the torchrun environment; single process when WORLD_SIZE is unset."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
+    """Contiguous blocks, remainder spread over the first ranks: rank r owns [start_r, start_r + count_r)."""
+    base, rem = divmod(n_items, world)
+    start = rank * base + min(rank, rem)
+    return list(range(start, start + base + (1 if rank < rem else 0)))
+
+
+def shard_capacity(n_items: int, world: int) -> int:
+    return (n_items + world - 1) // world
+
+
+def gather_answers(tokens: torch.Tensor, lengths: torch.Tensor, n_items: int, rank: int, world: int):
+    """Collate per-rank answers.  tokens [cap, max_new] int32 and lengths [cap] int32 (cap = shard_capacity; unused slots
+    have length -1) -> list of n_items token-id lists in global clip order, identical on every rank.
+    world == 1 short-circuits without touching torch.distributed."""
+    cap, width = tokens.shape
+    assert cap == shard_capacity(n_items, world) and lengths.shape == (cap,)
+    if world > 1:
+        packed = torch.cat([tokens.reshape(-1), lengths]).contiguous()
+        out = torch.empty(world * packed.numel(), dtype=packed.dtype, device=packed.device)
+        dist.all_gather_into_tensor(out, packed)
+        out = out.view(world, -1).cpu()
+    else:
+        out = torch.cat([tokens.reshape(-1), lengths]).view(1, -1).cpu()
+    answers: List[List[int]] = [None] * n_items
+    for r in range(world):
+        toks = out[r, : cap * width].view(cap, width)
+        lens = out[r, cap * width:]
+        for slot, idx in enumerate(shard_indices(n_items, r, world)):
+            n = int(lens[slot])
+            answers[idx] = toks[slot, :max(n, 0)].tolist()
+    return answers
+
+
+def run_sharded(n_items: int, infer_batch: Callable[[Sequence[int]], tuple], max_new_tokens: int, rank: int, world: int,
+                device, per_gpu_batch: int = 8):
+    """Run `infer_batch(indices) -> (tokens [len(indices), <=max_new] int tensor, lengths list)` over this rank's shard in
+    groups of `per_gpu_batch`, then collate.  A group that raises keeps its slots with length 0."""
+    mine = shard_indices(n_items, rank, world)
+    cap = shard_capacity(n_items, world)
+    tokens = torch.zeros(cap, max_new_tokens, dtype=torch.int32, device=device)
+    lengths = torch.full((cap,), -1, dtype=torch.int32, device=device)
+    for g0 in range(0, len(mine), per_gpu_batch):
+        group = mine[g0:g0 + per_gpu_batch]
+        try:
+            toks, lens = infer_batch(group)
+            for j in range(len(group)):
+                n = int(lens[j])
+                tokens[g0 + j, :n] = toks[j, :n].to(device=device, dtype=torch.int32)
+                lengths[g0 + j] = n
+        except Exception as e:                               # noqa: BLE001 -- same "print and continue" policy as the reference
+            print(f"[rank {rank}] Error processing clips {group}: {e}")
+            lengths[g0:g0 + len(group)] = 0
+    return gather_answers(tokens, lengths, n_items, rank, world)
