@@ -38,6 +38,7 @@ extern "C" int pgv_ctx_create(int device, pgv_ctx** out) {
 extern "C" void pgv_ctx_destroy(pgv_ctx* ctx) {
     if (!ctx) return;
     if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
     for (auto& f : ctx->fam)
         for (auto e : f.ev) (void)hipEventDestroy(e);
     delete ctx;

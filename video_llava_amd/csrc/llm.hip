@@ -354,10 +354,13 @@ static int decode_step(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int eos, int flags,
     } else {
         if (!kv->gexec || kv->g_B != B || kv->g_eos != eos || kv->g_flags != flags) {
             if (kv->gexec) { (void)hipGraphExecDestroy(kv->gexec); kv->gexec = nullptr; }
+            // capture on a library-owned stream (the caller's may be the legacy default stream, which cannot be
+            // captured); capture executes nothing, the instantiated graph is then launched on the caller's stream
             hipGraph_t graph = nullptr;
-            PGV_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed));
-            const int rc = decode_enqueue(ctx, m, kv, eos, flags, s);
-            hipError_t e = hipStreamEndCapture(s, &graph);
+            if (!ctx->cap_stream) PGV_HIP(hipStreamCreateWithFlags(&ctx->cap_stream, hipStreamNonBlocking));
+            PGV_HIP(hipStreamBeginCapture(ctx->cap_stream, hipStreamCaptureModeRelaxed));
+            const int rc = decode_enqueue(ctx, m, kv, eos, flags, ctx->cap_stream);
+            hipError_t e = hipStreamEndCapture(ctx->cap_stream, &graph);
             if (rc != PGV_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
             if (e != hipSuccess) { pgv_set_error("decode graph capture failed: %s", hipGetErrorString(e)); return PGV_EHIP; }
             e = hipGraphInstantiate(&kv->gexec, graph, nullptr, nullptr, 0);

@@ -54,6 +54,7 @@ struct pgv_ctx {
     size_t ws_off = 0;
     bool prof = false;
     pgv_prof_family fam[PGV_NFAMILY];
+    hipStream_t cap_stream = nullptr;   // used only to capture decode graphs
 };
 
 // Reserve the arena for a call (may hipMalloc: never call inside graph capture).
