@@ -182,6 +182,18 @@ enum pgv_epi {
 };
 int pgv_gemm(pgv_ctx *ctx, int dtype, int epi, const void *d_A, int lda, const void *d_W, int ldw, const float *d_bias,
              void *d_C, int ldc, int M, int N, int K, void *stream);
+/* CLIP self-attention on a fused qkv buffer [T*N, 3C] (q | k | v column blocks) -> [T*N, C]; head_dim 64, no mask
+ * (HF CLIPAttention eager math, HF:clip/modeling_clip.py:259-277). */
+int pgv_vit_attention(pgv_ctx *ctx, int dtype, const void *d_qkv, void *d_out, int T, int N, int C, int heads, void *stream);
+/* Decode-time projection y[B,N] = x[B,K] W[N,K]^T for B <= 16 (weights streamed once).  mode: 0 = 16-bit out,
+ * 1 = fp32 residual accumulate, 2 = SwiGLU (W rows interleaved [32 gate | 32 up], out [B, N/2]), 3 = fp32 out.
+ * d_W is in the fragment-blocked layout produced by pgv_pack_blocked (rows padded to a multiple of 16). */
+int pgv_gemv(pgv_ctx *ctx, int dtype, int mode, const void *d_W, const void *d_x, int ldx, void *d_out, int ldo, int N, int K,
+             int B, void *stream);
+/* Re-lay a row-major [rows, cols] 16-bit matrix (cols % 32 == 0) into the fragment-blocked layout
+ * [rows/16][cols/32][4 k-groups][16 rows][8 elems]: each 1 KiB block is one v_mfma_f32_16x16x32 A fragment in lane order.
+ * d_dst must hold ceil(rows/16)*16 * cols elements (zero it first when rows % 16 != 0). */
+int pgv_pack_blocked(pgv_ctx *ctx, int dtype, const void *d_src, int rows, int cols, void *d_dst, void *stream);
 int pgv_layernorm(pgv_ctx *ctx, int dtype, const float *d_x, const float *d_gamma, const float *d_beta, float eps,
                   void *d_y, int rows, int cols, void *stream);
 int pgv_rmsnorm(pgv_ctx *ctx, int dtype, const float *d_x, const float *d_gamma, float eps, void *d_y, int rows, int cols,

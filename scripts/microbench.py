@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""Kernel microbenchmarks at the BASELINE shapes (run on the MI355X box): per-kernel TFLOP/s or GB/s with HIP events,
+interleaved rounds, median/min.  Usage: python scripts/microbench.py [gemm] [attn] [gemv] [dattn] [norm]"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from video_llava_amd import _lib  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(iters):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record(); b.synchronize()
+        ts.append(a.elapsed_time(b))
+    ts.sort()
+    return ts[len(ts) // 2], ts[0]
+
+
+def bench_gemm(ctx, dtype=torch.bfloat16):
+    print("== gemm (M,N,K,epi) median/min ms, TF/s(median) ==")
+    frames = 400
+    M = frames * 257
+    shapes = [(M, 3072, 1024, _lib.EPI_BIAS, "vit qkv"), (M, 1024, 1024, _lib.EPI_BIAS_RESID, "vit out_proj"),
+              (M, 4096, 1024, _lib.EPI_BIAS_QGELU, "vit fc1"), (M, 1024, 4096, _lib.EPI_BIAS_RESID, "vit fc2"),
+              (25700, 3072, 1024, _lib.EPI_BIAS, "vit qkv 1 clip"), (25700, 1024, 4096, _lib.EPI_BIAS_RESID, "vit fc2 1 clip"),
+              (3632, 12288, 4096, _lib.EPI_NONE, "llm qkv B=8"), (3632, 22016, 4096, _lib.EPI_SWIGLU, "llm gate/up"),
+              (3632, 4096, 11008, _lib.EPI_RESID, "llm down"), (8192, 8192, 8192, _lib.EPI_NONE, "8192^3")]
+    for (m, n, k, epi, name) in shapes:
+        a = torch.randn(m, k, device=DEV).to(dtype)
+        w = (torch.randn(n, k, device=DEV) * 0.02).to(dtype)
+        bias = torch.randn(n, device=DEV) if epi in (_lib.EPI_BIAS, _lib.EPI_BIAS_RESID, _lib.EPI_BIAS_QGELU) else None
+        if epi in (_lib.EPI_RESID, _lib.EPI_BIAS_RESID):
+            out = torch.zeros(m, n, device=DEV)
+        elif epi == _lib.EPI_SWIGLU:
+            out = torch.empty(m, n // 2, device=DEV, dtype=dtype)
+        else:
+            out = torch.empty(m, n, device=DEV, dtype=dtype)
+        med, mn = timeit(lambda: ctx.gemm(a, w, bias, epi, out=out))
+        print(f"{name:18s} {m:7d} {n:6d} {k:6d} epi{epi}: {med:8.3f} / {mn:8.3f} ms  {2.0 * m * n * k / med / 1e9:8.1f} TF/s")
+        del a, w, out
+
+
+def bench_vit_attn(ctx, dtype=torch.bfloat16):
+    import ctypes as C
+    print("== vit attention ==")
+    lib = ctx.lib
+    for T, N in ((400, 257), (100, 257), (100, 577)):
+        qkv = torch.randn(T * N, 3072, device=DEV).to(dtype)
+        out = torch.empty(T * N, 1024, device=DEV, dtype=dtype)
+        f = lambda: _lib.check(lib.pgv_vit_attention(ctx.handle, _lib.dtype_code(dtype), qkv.data_ptr(), out.data_ptr(), T, N, 1024, 16, _lib.stream_ptr()))
+        med, mn = timeit(f)
+        fl = 4.0 * T * 16 * N * N * 64
+        print(f"T={T} N={N}: {med:8.3f} / {mn:8.3f} ms  {fl / med / 1e9:8.1f} TF/s")
+
+
+def bench_decode(ctx, dtype=torch.bfloat16):
+    import ctypes as C
+    lib = ctx.lib
+    print("== decode gemv (mode, N, K, B) median/min us, GB/s ==")
+    # rotate through several weight copies so the 256 MB Infinity Cache cannot serve the stream
+    for (mode, N, K, name) in ((0, 12288, 4096, "qkv"), (1, 4096, 4096, "o_proj"), (2, 22016, 4096, "gate/up"), (1, 4096, 11008, "down"),
+                               (3, 32003, 4096, "lm_head")):
+        for B in (8, 16):
+            ncopy = max(2, int(600e6 // (N * K * 2)) + 1)
+            ws = []
+            Np = (N + 15) // 16 * 16
+            for _ in range(ncopy):
+                src = (torch.randn(N, K, device=DEV) * 0.02).to(dtype)
+                dst = torch.zeros(Np, K, device=DEV, dtype=dtype)
+                _lib.check(lib.pgv_pack_blocked(ctx.handle, _lib.dtype_code(dtype), src.data_ptr(), N, K, dst.data_ptr(), _lib.stream_ptr()))
+                ws.append(dst)
+            torch.cuda.synchronize()
+            x = torch.randn(B, K, device=DEV).to(dtype)
+            if mode == 1:
+                out = torch.zeros(B, N, device=DEV)
+            elif mode == 3:
+                out = torch.empty(B, N, device=DEV)
+            elif mode == 2:
+                out = torch.empty(B, N // 2, device=DEV, dtype=dtype)
+            else:
+                out = torch.empty(B, N, device=DEV, dtype=dtype)
+            state = {"i": 0}
+
+            def f():
+                w = ws[state["i"] % ncopy]; state["i"] += 1
+                _lib.check(lib.pgv_gemv(ctx.handle, _lib.dtype_code(dtype), mode, w.data_ptr(), x.data_ptr(), K, out.data_ptr(),
+                                            out.shape[1], N, K, B, _lib.stream_ptr()))
+            med, mn = timeit(f, iters=40)
+            print(f"{name:8s} mode{mode} N={N:6d} K={K:6d} B={B:2d}: {med * 1e3:8.1f} / {mn * 1e3:8.1f} us  {N * K * 2 / med / 1e6:8.1f} GB/s")
+            del ws
+
+
+if __name__ == "__main__":
+    which = set(sys.argv[1:]) or {"gemm", "attn", "gemv"}
+    ctx = _lib.Context.get(0)
+    if "gemm" in which:
+        bench_gemm(ctx)
+    if "attn" in which:
+        bench_vit_attn(ctx)
+    if "gemv" in which:
+        bench_decode(ctx)

@@ -152,3 +152,34 @@ def test_kv_bounds_and_errors(ctx):
         m.decode_greedy(kv, nxt, 1)                     # 3 + 61 = 64 tokens: full
     with pytest.raises(ValueError, match="outside the vocabulary"):
         m.prefill([[1, 99999]], None, 64)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 1e-3), (torch.bfloat16, 8e-3)])
+@pytest.mark.parametrize("mode,N,K,B", [(0, 1536, 512, 3), (1, 512, 768, 8), (2, 1536, 512, 16), (3, 515, 512, 5), (0, 12288, 4096, 8)])
+def test_gemv_building_block(ctx, dtype, tol, mode, N, K, B):
+    """pgv_gemv on fragment-blocked weights (pgv_pack_blocked) vs torch fp32, every epilogue mode."""
+    from video_llava_amd import _lib
+    g = torch.Generator().manual_seed(N + K + B)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dtype)
+    x = torch.randn(B, K, generator=g).to(dtype)
+    Np = (N + 15) // 16 * 16
+    wd = w.to(DEV)
+    wb = torch.zeros(Np, K, dtype=dtype, device=DEV)
+    _lib.check(ctx.lib.pgv_pack_blocked(ctx.handle, _lib.dtype_code(dtype), wd.data_ptr(), N, K, wb.data_ptr(), _lib.stream_ptr()))
+    xd = x.to(DEV)
+    y_ref = x.float() @ w.float().t()
+    if mode == 0:
+        out = torch.empty(B, N, dtype=dtype, device=DEV)
+    elif mode == 1:
+        r0 = torch.randn(B, N, generator=g)
+        out = r0.to(DEV).clone()
+        y_ref = r0 + y_ref
+    elif mode == 2:
+        out = torch.empty(B, N // 2, dtype=dtype, device=DEV)
+        yy = y_ref.view(B, N // 64, 2, 32)
+        y_ref = (torch.nn.functional.silu(yy[:, :, 0]) * yy[:, :, 1]).reshape(B, N // 2)
+    else:
+        out = torch.empty(B, N, dtype=torch.float32, device=DEV)
+    _lib.check(ctx.lib.pgv_gemv(ctx.handle, _lib.dtype_code(dtype), mode, wb.data_ptr(), xd.data_ptr(), K, out.data_ptr(), out.shape[1],
+                                N, K, B, _lib.stream_ptr()))
+    assert rel(out, y_ref) < (tol if mode in (0, 2) else 1e-5 + (2e-5 if mode == 3 else 0))

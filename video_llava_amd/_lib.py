@@ -65,6 +65,9 @@ PROTOTYPES = {
     "pgv_llm_decode": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pgv_llm_decode_greedy": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "pgv_gemm": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "pgv_vit_attention": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "pgv_gemv": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    "pgv_pack_blocked": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp]),
     "pgv_layernorm": (_i, [_vp, _i, _vp, _vp, _vp, _f, _vp, _i, _i, _vp]),
     "pgv_rmsnorm": (_i, [_vp, _i, _vp, _vp, _f, _vp, _i, _i, _vp]),
 }

@@ -29,6 +29,7 @@ struct KArgs {
     int lda, ldw, ldc;      // elements
     int M, N, K;            // logical sizes (N = output columns before SWIGLU halving)
     int ntm, ntn;
+    int wblk;               // W is in the fragment-blocked layout (weights.h) instead of row-major
 };
 
 __device__ __forceinline__ float quick_gelu_f(float x) { return x / (1.0f + __expf(-1.702f * x)); }
@@ -62,8 +63,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(KArgs p) {
         int ra = min(m0 + row, p.M - 1);
         int rw = min(n0 + row, p.N - 1);
         ga[j] = p.A + ((size_t)ra * p.lda + chunk * 8) * 2;
-        gw[j] = p.W + ((size_t)rw * p.ldw + chunk * 8) * 2;
+        if (p.wblk)   // block (rw/16, k/32): chunk c of the 64-wide K tile lives in block c/4 at slot (c%4)*16 + rw%16
+            gw[j] = p.W + (((size_t)(rw >> 4) * (p.K >> 5) + (chunk >> 2)) * 512 + (((chunk & 3) << 4) + (rw & 15)) * 8) * 2;
+        else
+            gw[j] = p.W + ((size_t)rw * p.ldw + chunk * 8) * 2;
     }
+    const size_t wstep = p.wblk ? 2048 : (size_t)BK * 2;     // bytes per K tile on the W side
     auto stage = [&](int buf, int kt) {
         char* base = smem + buf * STAGE_BYTES;
         const size_t koff = (size_t)kt * BK * 2;
@@ -74,7 +79,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_256(KArgs p) {
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw[j] + koff),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gw[j] + (size_t)kt * wstep),
                                              (__attribute__((address_space(3))) void*)(base + TILE_BYTES + (j * 8 + w) * 1024), 16, 0, 0);
         }
     };
@@ -232,6 +237,8 @@ int pgv_launch_gemm(pgv_ctx* ctx, int dtype, const GemmArgs& a, hipStream_t s) {
     k.A = (const char*)a.A; k.W = (const char*)a.W; k.bias = a.bias; k.C = (char*)a.C;
     k.lda = a.lda; k.ldw = a.ldw; k.ldc = a.ldc; k.M = a.M; k.N = a.N; k.K = a.K;
     k.ntm = (a.M + BM - 1) / BM; k.ntn = (a.N + BN - 1) / BN;
+    k.wblk = a.w_blocked ? 1 : 0;
+    PGV_CHECK(!a.w_blocked || a.N % 16 == 0, "gemm: blocked weights need N %% 16 == 0");
     const int grid = k.ntm * k.ntn;
     pgv_prof_begin(ctx, 0, s);
     int rc;

@@ -74,7 +74,7 @@ extern "C" int pgv_llm_create(pgv_ctx* ctx, const pgv_llm_config* cfg, int dtype
     PGV_CHECK(cfg->vocab > 0 && cfg->layers >= 0, "pgv_llm_create: bad vocab/layers");
     pgv_llm* m = new pgv_llm();
     m->ctx = ctx; m->cfg = *cfg; m->dtype = dtype;
-    m->vocab_cap = cfg->vocab + 64;
+    m->vocab_cap = (cfg->vocab + 64 + 15) / 16 * 16;   // lm_head is fragment-blocked: rows padded to 16 (zero rows)
     const size_t H = cfg->hidden, I = cfg->inter, V = m->vocab_cap, L = cfg->layers;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += pgv_align(bytes); return o; };
@@ -88,6 +88,7 @@ extern "C" int pgv_llm_create(pgv_ctx* ctx, const pgv_llm_config* cfg, int dtype
     hipError_t e = hipMalloc((void**)&m->blob, off);
     if (e != hipSuccess) { delete m; pgv_set_error("pgv_llm_create: hipMalloc(%zu MiB): %s", off >> 20, hipGetErrorString(e)); return PGV_ENOMEM; }
     m->blob_bytes = off;
+    (void)hipMemset(m->blob + o_head, 0, V * H * 2);     // padded lm_head rows must be finite
     char* b = m->blob;
     m->embed = b + o_embed; m->lm_head = b + o_head; m->norm_g = (float*)(b + o_norm); m->rope = (float*)(b + o_rope);
     m->layers.resize(L);
@@ -129,7 +130,7 @@ extern "C" int pgv_llm_resize_vocab(pgv_llm* m, int new_vocab, void* stream) {
     if (new_vocab > m->cfg.vocab) {
         const size_t off = (size_t)m->cfg.vocab * H * 2, bytes = (size_t)(new_vocab - m->cfg.vocab) * H * 2;
         PGV_HIP(hipMemsetAsync((char*)m->embed + off, 0, bytes, (hipStream_t)stream));
-        PGV_HIP(hipMemsetAsync((char*)m->lm_head + off, 0, bytes, (hipStream_t)stream));
+        // lm_head is fragment-blocked (rows interleaved inside 1 KiB blocks); its spare rows were zeroed at creation
     }
     m->cfg.vocab = new_vocab;
     return PGV_OK;
@@ -141,7 +142,7 @@ extern "C" int pgv_llm_load_rows(pgv_llm* m, const char* name, const void* data,
     PackDst d;
     d.dst_dtype = m->dtype; d.rows = nrows; d.cols = m->cfg.hidden; d.dst_stride = d.cols; d.row_off = row0;
     if (!strcmp(name, "model.embed_tokens.weight")) d.ptr = m->embed;
-    else if (!strcmp(name, "lm_head.weight")) d.ptr = m->lm_head;
+    else if (!strcmp(name, "lm_head.weight")) { d.ptr = m->lm_head; d.blocked = true; }
     else { pgv_set_error("pgv_llm_load_rows: '%s' is not a vocabulary matrix", name); return PGV_ENAME; }
     PGV_TRY(pgv_pack_tensor(d, data, src_dtype, on_device, (hipStream_t)stream));
     m->loaded.insert(name);
@@ -156,7 +157,7 @@ extern "C" int pgv_llm_load_tensor(pgv_llm* m, const char* name_in, const void* 
     auto vec = [&](float* ptr, long long n) { d.ptr = ptr; d.rows = 1; d.cols = n; };
     auto mat = [&](void* ptr, long long r, long long c, long long roff) { d.ptr = ptr; d.dst_dtype = m->dtype; d.rows = r; d.cols = c; d.row_off = roff; };
     if (name == "model.embed_tokens.weight") mat(m->embed, V, H, 0);
-    else if (name == "lm_head.weight") mat(m->lm_head, V, H, 0);
+    else if (name == "lm_head.weight") { mat(m->lm_head, V, H, 0); d.blocked = true; }
     else if (name == "model.norm.weight") vec(m->norm_g, H);
     else if (name.rfind("model.layers.", 0) == 0) {
         const char* p = name.c_str() + 13;
@@ -165,13 +166,13 @@ extern "C" int pgv_llm_load_tensor(pgv_llm* m, const char* name_in, const void* 
         if (end == p || *end != '.' || li < 0 || li >= m->cfg.layers) { pgv_set_error("pgv_llm_load_tensor: bad layer index in '%s'", name_in); return PGV_ENAME; }
         std::string rest(end + 1);
         LlmLayer& l = m->layers[li];
-        if (rest == "self_attn.q_proj.weight") mat(l.wqkv, H, H, 0);
-        else if (rest == "self_attn.k_proj.weight") mat(l.wqkv, H, H, H);
-        else if (rest == "self_attn.v_proj.weight") mat(l.wqkv, H, H, 2 * H);
-        else if (rest == "self_attn.o_proj.weight") mat(l.wo, H, H, 0);
-        else if (rest == "mlp.gate_proj.weight") { mat(l.wgu, I, H, 0); d.row_blk = 32; d.blk_stride = 64; }       // [32 gate | 32 up] per 64 rows
-        else if (rest == "mlp.up_proj.weight") { mat(l.wgu, I, H, 32); d.row_blk = 32; d.blk_stride = 64; }
-        else if (rest == "mlp.down_proj.weight") mat(l.wdown, H, I, 0);
+        if (rest == "self_attn.q_proj.weight") { mat(l.wqkv, H, H, 0); d.blocked = true; }
+        else if (rest == "self_attn.k_proj.weight") { mat(l.wqkv, H, H, H); d.blocked = true; }
+        else if (rest == "self_attn.v_proj.weight") { mat(l.wqkv, H, H, 2 * H); d.blocked = true; }
+        else if (rest == "self_attn.o_proj.weight") { mat(l.wo, H, H, 0); d.blocked = true; }
+        else if (rest == "mlp.gate_proj.weight") { mat(l.wgu, I, H, 0); d.row_blk = 32; d.blk_stride = 64; d.blocked = true; }       // [32 gate | 32 up] per 64 rows
+        else if (rest == "mlp.up_proj.weight") { mat(l.wgu, I, H, 32); d.row_blk = 32; d.blk_stride = 64; d.blocked = true; }
+        else if (rest == "mlp.down_proj.weight") { mat(l.wdown, H, I, 0); d.blocked = true; }
         else if (rest == "input_layernorm.weight") vec(l.in_g, H);
         else if (rest == "post_attention_layernorm.weight") vec(l.post_g, H);
         else if (rest == "self_attn.rotary_emb.inv_freq") return PGV_OK;
@@ -293,16 +294,16 @@ extern "C" int pgv_llm_prefill(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, const int32
         const LlmLayer& l = m->layers[li];
         PGV_TRY(pgv_launch_rmsnorm(m->dtype, resid, l.in_g, m->cfg.eps, xn, M, H, s));
         GemmArgs g{};
-        g.A = xn; g.lda = H; g.W = l.wqkv; g.ldw = H; g.bias = nullptr; g.C = qkv; g.ldc = 3 * H; g.M = M; g.N = 3 * H; g.K = H; g.epi = PGV_EPI_NONE;
+        g.A = xn; g.lda = H; g.W = l.wqkv; g.ldw = H; g.bias = nullptr; g.C = qkv; g.ldc = 3 * H; g.M = M; g.N = 3 * H; g.K = H; g.epi = PGV_EPI_NONE; g.w_blocked = true;
         PGV_TRY(pgv_launch_gemm(ctx, m->dtype, g, s));
         PGV_TRY(pgv_launch_rope_kv_write(m->dtype, qkv, d_row_b, d_row_pos, m->rope, kv->Kc[li], kv->Vc[li], M, H, heads, kv->max_seq, s));
         PGV_TRY(pgv_launch_prefill_attn(ctx, m->dtype, qkv, ao, kv->Kc[li], kv->Vc[li], d_cu, B, max_len, H, heads, kv->max_seq, attn_flops, s));
-        g = GemmArgs{}; g.A = ao; g.lda = H; g.W = l.wo; g.ldw = H; g.C = resid; g.ldc = H; g.M = M; g.N = H; g.K = H; g.epi = PGV_EPI_RESID;
+        g = GemmArgs{}; g.A = ao; g.lda = H; g.W = l.wo; g.ldw = H; g.C = resid; g.ldc = H; g.M = M; g.N = H; g.K = H; g.epi = PGV_EPI_RESID; g.w_blocked = true;
         PGV_TRY(pgv_launch_gemm(ctx, m->dtype, g, s));
         PGV_TRY(pgv_launch_rmsnorm(m->dtype, resid, l.post_g, m->cfg.eps, xn, M, H, s));
-        g = GemmArgs{}; g.A = xn; g.lda = H; g.W = l.wgu; g.ldw = H; g.C = act; g.ldc = I; g.M = M; g.N = 2 * I; g.K = H; g.epi = PGV_EPI_SWIGLU;
+        g = GemmArgs{}; g.A = xn; g.lda = H; g.W = l.wgu; g.ldw = H; g.C = act; g.ldc = I; g.M = M; g.N = 2 * I; g.K = H; g.epi = PGV_EPI_SWIGLU; g.w_blocked = true;
         PGV_TRY(pgv_launch_gemm(ctx, m->dtype, g, s));
-        g = GemmArgs{}; g.A = act; g.lda = I; g.W = l.wdown; g.ldw = I; g.C = resid; g.ldc = H; g.M = M; g.N = H; g.K = I; g.epi = PGV_EPI_RESID;
+        g = GemmArgs{}; g.A = act; g.lda = I; g.W = l.wdown; g.ldw = I; g.C = resid; g.ldc = H; g.M = M; g.N = H; g.K = I; g.epi = PGV_EPI_RESID; g.w_blocked = true;
         PGV_TRY(pgv_launch_gemm(ctx, m->dtype, g, s));
     }
     // lm_head only on the last position of every sequence (the reference computes all S positions, video_chatgpt.py:226)

@@ -239,9 +239,10 @@ __global__ __launch_bounds__(256) void prefill_attn_kernel(PrefillAttnArgs p) {
 
 // ---------------------------------------------------------------------------------------------
 // decode GEMV on MFMA: y[b, n] = sum_k x[b, k] W[n, k], B <= 16.
-// Workgroup = 8 waves, owns TILES blocks of 16 weight rows; wave w takes k-steps (32 wide) w, w+8, ... so the 8 waves
-// read adjacent 64-B pieces of the same rows.  A operand = W fragment (lane: row l&15, k (l>>4)*8..+8, one 16-B load),
-// B operand = x fragment (lane: batch l&15, same k) served by L2.  Partial 16x16 tiles are reduced through LDS.
+// W is stored in the fragment-blocked layout (weights.h): block (n/16, k/32) is the 1 KiB a wave loads as ONE
+// v_mfma_f32_16x16x32 A fragment, so every wave-load is a single contiguous, fully coalesced 1 KiB burst.
+// Workgroup = 8 waves, owns TILES row blocks; wave w takes k-steps w, w+8, ... (adjacent KiBs of the same row block).
+// B operand = x fragment (lane: batch l&15, k (l>>4)*8..+8) served by L2.  Partial 16x16 tiles are reduced through LDS.
 // ---------------------------------------------------------------------------------------------
 enum { GV_STORE16 = 0, GV_RESID = 1, GV_SWIGLU = 2, GV_F32 = 3 };
 
@@ -257,31 +258,31 @@ __global__ __launch_bounds__(512) void gemv_mfma_kernel(GemvArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kg = lane >> 4;
-    int row[TILES];
+    const int kblocks = p.K >> 5;
+    int rb[TILES];
     if constexpr (MODE == GV_SWIGLU) {
         const int i0 = blockIdx.x * 16;                          // output column block
-        const int base = (i0 >> 5) * 64 + (i0 & 31);
-        row[0] = base + l15;                                     // gate rows
-        row[1] = base + 32 + l15;                                // up rows
+        const int base = (i0 >> 5) * 64 + (i0 & 31);             // packed gate row (multiple of 16)
+        rb[0] = base >> 4;                                       // gate row block
+        rb[1] = (base + 32) >> 4;                                // matching up row block
     } else {
-        row[0] = min(blockIdx.x * 16 + l15, p.N - 1);
+        rb[0] = blockIdx.x;
     }
     const char* wp[TILES];
 #pragma unroll
-    for (int t = 0; t < TILES; ++t) wp[t] = p.W + ((size_t)row[t] * p.K + kg * 8) * 2;
+    for (int t = 0; t < TILES; ++t) wp[t] = p.W + ((size_t)rb[t] * kblocks) * 1024 + lane * 16;
     const char* xp = p.x + ((size_t)min(l15, p.B - 1) * p.ldx + kg * 8) * 2;
     f32x4_t acc[TILES];
 #pragma unroll
     for (int t = 0; t < TILES; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    const int nsteps = p.K / 32;
-    constexpr int U = 4;
+    constexpr int U = (TILES == 2) ? 4 : 8;
     int kk = w;
-    for (; kk + 8 * (U - 1) < nsteps; kk += 8 * U) {
+    for (; kk + 8 * (U - 1) < kblocks; kk += 8 * U) {
         typename T::v8 wf[U][TILES], xf[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
 #pragma unroll
-            for (int t = 0; t < TILES; ++t) wf[u][t] = __builtin_nontemporal_load((const typename T::v8*)(wp[t] + (size_t)(kk + 8 * u) * 64));
+            for (int t = 0; t < TILES; ++t) wf[u][t] = __builtin_nontemporal_load((const typename T::v8*)(wp[t] + (size_t)(kk + 8 * u) * 1024));
             xf[u] = *(const typename T::v8*)(xp + (size_t)(kk + 8 * u) * 64);
         }
 #pragma unroll
@@ -289,11 +290,11 @@ __global__ __launch_bounds__(512) void gemv_mfma_kernel(GemvArgs p) {
 #pragma unroll
             for (int t = 0; t < TILES; ++t) acc[t] = T::mfma16(wf[u][t], xf[u], acc[t]);
     }
-    for (; kk < nsteps; kk += 8) {
+    for (; kk < kblocks; kk += 8) {
         const typename T::v8 xf = *(const typename T::v8*)(xp + (size_t)kk * 64);
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
-            const typename T::v8 wf = __builtin_nontemporal_load((const typename T::v8*)(wp[t] + (size_t)kk * 64));
+            const typename T::v8 wf = __builtin_nontemporal_load((const typename T::v8*)(wp[t] + (size_t)kk * 1024));
             acc[t] = T::mfma16(wf, xf, acc[t]);
         }
     }
@@ -331,19 +332,20 @@ __global__ __launch_bounds__(512) void gemv_mfma_kernel(GemvArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// decode attention: one workgroup per (sequence, head); 4 waves; lane = (key slot 0..3, 16-B d chunk 0..15).
-// Applies RoPE to the fresh q/k, appends k/v to the cache at pos[b], attends over keys [0, pos].
+// decode attention: one workgroup of 8 waves per (sequence, head); lane = (key slot 0..3, 16-B d chunk 0..15), so a
+// wave-load covers 4 consecutive cache rows = 1 KiB contiguous.  Each lane keeps TWO independent online-softmax states
+// (keys k and k+32 of every 64-key round) and prefetches the next round, i.e. 8 x 16-B loads in flight per lane.
+// Applies RoPE to the fresh q/k, appends k/v to the cache at pos[b], attends over keys [0, pos]; the 64 partial states
+// are merged through LDS.
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void decode_attn_kernel(const typename T::elem* __restrict__ qkv, const int* __restrict__ pos_arr,
+__global__ __launch_bounds__(512) void decode_attn_kernel(const typename T::elem* __restrict__ qkv, const int* __restrict__ pos_arr,
                                                           const float2* __restrict__ rope, typename T::elem* __restrict__ Kc,
                                                           typename T::elem* __restrict__ Vc, typename T::elem* __restrict__ out, int H, int heads,
                                                           int max_seq, float scale_log2e) {
     __shared__ float qs[HD];
-    __shared__ __attribute__((aligned(16))) typename T::elem ks[HD];
-    __shared__ __attribute__((aligned(16))) typename T::elem vs[HD];
-    __shared__ float st_m[16], st_l[16];
-    __shared__ float st_o[16][HD];
+    __shared__ float st_m[64], st_l[64];
+    __shared__ float st_o[64][HD + 4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int h = blockIdx.x, b = blockIdx.y;
     const int pos = pos_arr[b];
@@ -352,57 +354,79 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const typename T::elem
     const typename T::elem* v = q + 2 * H;
     typename T::elem* kcache = Kc + ((size_t)b * heads + h) * max_seq * HD;
     typename T::elem* vcache = Vc + ((size_t)b * heads + h) * max_seq * HD;
+    // fresh token: rotate q (-> LDS, rounded to the activation dtype like the prefill path), rotate k and append k, v
     if (tid < 64) {
         const float2 cs = rope[(size_t)pos * 64 + tid];
         const float q1 = (float)q[tid], q2 = (float)q[tid + 64];
-        qs[tid] = (float)T::from_f32(q1 * cs.x - q2 * cs.y);          // rounded to the activation dtype like the prefill path
+        qs[tid] = (float)T::from_f32(q1 * cs.x - q2 * cs.y);
         qs[tid + 64] = (float)T::from_f32(q2 * cs.x + q1 * cs.y);
     } else if (tid < 128) {
         const int j = tid - 64;
         const float2 cs = rope[(size_t)pos * 64 + j];
         const float k1 = (float)k[j], k2 = (float)k[j + 64];
-        const typename T::elem a = T::from_f32(k1 * cs.x - k2 * cs.y), c = T::from_f32(k2 * cs.x + k1 * cs.y);
-        ks[j] = a; ks[j + 64] = c;
-        kcache[(size_t)pos * HD + j] = a; kcache[(size_t)pos * HD + j + 64] = c;
-    } else {
+        kcache[(size_t)pos * HD + j] = T::from_f32(k1 * cs.x - k2 * cs.y);
+        kcache[(size_t)pos * HD + j + 64] = T::from_f32(k2 * cs.x + k1 * cs.y);
+    } else if (tid < 256) {
         const int j = tid - 128;
-        const typename T::elem a = v[j];
-        vs[j] = a;
-        vcache[(size_t)pos * HD + j] = a;
+        vcache[(size_t)pos * HD + j] = v[j];
     }
+    // the appended row is read back below by other waves of this workgroup: make the stores visible CU-wide first
+    __threadfence_block();
     __syncthreads();
     const int slot = lane >> 4, dc = lane & 15;
     float qr[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) qr[e] = qs[dc * 8 + e] * scale_log2e;
-    float m = -1e30f, l = 0.f, o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int key = w * 4 + slot; key <= pos; key += 16) {
-        typename T::v8 kv8, vv8;
-        if (key == pos) { kv8 = *(const typename T::v8*)(ks + dc * 8); vv8 = *(const typename T::v8*)(vs + dc * 8); }
-        else { kv8 = *(const typename T::v8*)(kcache + (size_t)key * HD + dc * 8); vv8 = *(const typename T::v8*)(vcache + (size_t)key * HD + dc * 8); }
-        float s = 0.f;
+    float m[2] = {-1e30f, -1e30f}, l[2] = {0.f, 0.f}, o[2][8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s += qr[e] * (float)kv8[e];
-        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
-        const float mn = fmaxf(m, s);
-        const float alpha = exp2f(m - mn), pv = exp2f(s - mn);
-        m = mn;
-        l = l * alpha + pv;
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = o[e] * alpha + pv * (float)vv8[e];
+        for (int e = 0; e < 8; ++e) o[u][e] = 0.f;
+    const int n_keys = pos + 1;
+    const int key0 = w * 4 + slot;
+    typename T::v8 kf[2], vf[2], kn[2], vn[2];
+    auto load = [&](int key, typename T::v8& kk_, typename T::v8& vv_) {
+        const int kc = min(key, n_keys - 1);               // clamped rows are masked below
+        kk_ = *(const typename T::v8*)(kcache + (size_t)kc * HD + dc * 8);
+        vv_ = *(const typename T::v8*)(vcache + (size_t)kc * HD + dc * 8);
+    };
+    load(key0, kf[0], vf[0]);
+    load(key0 + 32, kf[1], vf[1]);
+    for (int base = key0; base < n_keys; base += 64) {
+        if (base + 64 < n_keys) { load(base + 64, kn[0], vn[0]); load(base + 96, kn[1], vn[1]); }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int key = base + 32 * u;
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += qr[e] * (float)kf[u][e];
+            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+            if (key < n_keys) {
+                const float mn = fmaxf(m[u], s);
+                const float alpha = exp2f(m[u] - mn), pv = exp2f(s - mn);
+                m[u] = mn;
+                l[u] = l[u] * alpha + pv;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[u][e] = o[u][e] * alpha + pv * (float)vf[u][e];
+            }
+        }
+        kf[0] = kn[0]; vf[0] = vn[0]; kf[1] = kn[1]; vf[1] = vn[1];
     }
-    const int sid = w * 4 + slot;
-    if (dc == 0) { st_m[sid] = m; st_l[sid] = l; }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) st_o[sid][dc * 8 + e] = o[e];
+    for (int u = 0; u < 2; ++u) {
+        const int sid = (w * 4 + slot) * 2 + u;
+        if (dc == 0) { st_m[sid] = m[u]; st_l[sid] = l[u]; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) st_o[sid][dc * 8 + e] = o[u][e];
+    }
     __syncthreads();
     if (tid < HD) {
         float M = -1e30f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) M = fmaxf(M, st_m[i]);
+#pragma unroll 8
+        for (int i = 0; i < 64; ++i) M = fmaxf(M, st_m[i]);
         float L = 0.f, acc = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
+#pragma unroll 8
+        for (int i = 0; i < 64; ++i) {
             const float f = exp2f(st_m[i] - M);
             L += st_l[i] * f;
             acc += st_o[i][tid] * f;
@@ -495,6 +519,7 @@ int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void
     GemvArgs a;
     a.W = (const char*)W; a.x = (const char*)x; a.out = (char*)out; a.N = N; a.K = K; a.B = B; a.ldx = ldx; a.ldo = ldo;
     int grid;
+    // W must be in the fragment-blocked layout with its row count padded to a multiple of 16 (zero rows)
     if (mode == GV_SWIGLU) { PGV_CHECK(N % 64 == 0, "gemv swiglu: N=%d must be a multiple of 64", N); grid = N / 32; }
     else { if (mode != GV_F32) PGV_CHECK(N % 16 == 0, "gemv: N=%d must be a multiple of 16", N); grid = (N + 15) / 16; }
     pgv_prof_begin(ctx, 3, s);
@@ -515,7 +540,7 @@ int pgv_launch_decode_attn(pgv_ctx* ctx, int dtype, const void* qkv, const int* 
                            int heads, int max_seq, double bytes, hipStream_t s) {
     const float sc = 0.08838834764831845f * 1.4426950408889634f;
     pgv_prof_begin(ctx, 4, s);
-    PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((decode_attn_kernel<T>), dim3(heads, B), dim3(256), 0, s, (const typename T::elem*)qkv, pos,
+    PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((decode_attn_kernel<T>), dim3(heads, B), dim3(512), 0, s, (const typename T::elem*)qkv, pos,
                                                     (const float2*)rope, (typename T::elem*)Kc, (typename T::elem*)Vc, (typename T::elem*)out, H, heads,
                                                     max_seq, sc));
     pgv_prof_end(ctx, 4, s, 0.0, bytes);
@@ -526,4 +551,18 @@ int pgv_launch_argmax(const float* logits, int V, int B, int* next, int* pos, in
                       hipStream_t s) {
     hipLaunchKernelGGL(argmax_kernel, dim3(B), dim3(1024), 0, s, logits, V, next, pos, step, hist, hist_stride, done, eos, advance);
     return PGV_OK;
+}
+
+extern "C" int pgv_gemv(pgv_ctx* ctx, int dtype, int mode, const void* d_W, const void* d_x, int ldx, void* d_out, int ldo, int N, int K, int B,
+                        void* stream) {
+    PGV_CHECK(ctx && d_W && d_x && d_out, "pgv_gemv: null argument");
+    return pgv_launch_gemv(ctx, dtype, mode, d_W, d_x, ldx, d_out, ldo, N, K, B, (hipStream_t)stream);
+}
+
+#include "weights.h"
+extern "C" int pgv_pack_blocked(pgv_ctx* ctx, int dtype, const void* d_src, int rows, int cols, void* d_dst, void* stream) {
+    PGV_CHECK(ctx && d_src && d_dst && rows > 0 && cols > 0 && cols % 32 == 0, "pgv_pack_blocked: bad arguments");
+    PackDst d;
+    d.ptr = d_dst; d.dst_dtype = dtype; d.rows = rows; d.cols = cols; d.dst_stride = cols; d.blocked = true;
+    return pgv_pack_tensor(d, d_src, dtype, 1, (hipStream_t)stream);
 }

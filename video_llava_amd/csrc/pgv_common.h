@@ -151,5 +151,6 @@ struct GemmArgs {
     void* C; int ldc;             // 16-bit / fp32 out, or fp32 residual (RESID epilogues)
     int M, N, K;
     int epi;
+    bool w_blocked = false;       // W in the fragment-blocked layout (weights.h) -- the decoder's packed weights
 };
 int pgv_launch_gemm(pgv_ctx* ctx, int dtype, const GemmArgs& a, hipStream_t s);

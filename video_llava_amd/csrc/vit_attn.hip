@@ -206,3 +206,8 @@ int pgv_launch_vit_attn(pgv_ctx* ctx, int dtype, const void* qkv, int ld, void* 
     pgv_prof_end(ctx, 1, s, 4.0 * (double)T * heads * (double)N * N * HD, 2.0 * 4.0 * (double)T * N * C);
     return PGV_OK;
 }
+
+extern "C" int pgv_vit_attention(pgv_ctx* ctx, int dtype, const void* d_qkv, void* d_out, int T, int N, int C, int heads, void* stream) {
+    PGV_CHECK(ctx && d_qkv && d_out && T > 0 && N > 0, "pgv_vit_attention: bad arguments");
+    return pgv_launch_vit_attn(ctx, dtype, d_qkv, 3 * C, d_out, C, T, N, C, heads, (hipStream_t)stream);
+}

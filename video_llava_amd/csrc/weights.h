@@ -15,7 +15,14 @@ struct PackDst {
     long long row_blk = 0;          // 0: dst_row = r + row_off;  else dst_row = (r / row_blk) * blk_stride + r % row_blk + row_off
     long long blk_stride = 0;
     long long row_off = 0;
+    // blocked = true: destination is the MFMA-fragment-blocked layout [rows/16][cols/32][kgroup 4][row 16][8 elems]
+    // (one 1 KiB block = exactly what one wave loads for a 16x16x32 A fragment); cols must be a multiple of 32.
+    bool blocked = false;
 };
+// element offset of (row, col) in the blocked layout of a [rows, cols] matrix
+inline __host__ __device__ long long pgv_blocked_offset(long long row, long long col, long long cols) {
+    return ((row >> 4) * (cols >> 5) + (col >> 5)) * 512 + ((((col & 31) >> 3) << 4) + (row & 15)) * 8 + (col & 7);
+}
 
 // Enqueue the conversion on `s`.  Host sources are staged through a temporary device buffer (synchronous).
 int pgv_pack_tensor(const PackDst& d, const void* data, int src_dtype, int on_device, hipStream_t s);
