@@ -50,6 +50,18 @@ def bench_gemm(ctx, dtype=torch.bfloat16):
         del a, w, out
 
 
+def bench_gemm_ablate(ctx, dtype=torch.bfloat16):
+    """8-phase kernel (PGV_GEMM_CFG=3) with PGV_GEMM_ABLATE set by the caller: epilogue BIAS shapes only."""
+    print("== gemm ablation (ABLATE=%s) ==" % os.environ.get("PGV_GEMM_ABLATE", "0"))
+    for (m, n, k, name) in ((102800, 3072, 1024, "vit qkv"), (8192, 8192, 8192, "8192^3"), (16384, 4096, 16384, "long K")):
+        a = torch.randn(m, k, device=DEV).to(dtype)
+        w = (torch.randn(n, k, device=DEV) * 0.02).to(dtype)
+        bias = torch.randn(n, device=DEV)
+        out = torch.empty(m, n, device=DEV, dtype=dtype)
+        med, mn = timeit(lambda: ctx.gemm(a, w, bias, _lib.EPI_BIAS, out=out))
+        print(f"{name:10s} {m:7d} {n:6d} {k:6d}: {med:8.3f} / {mn:8.3f} ms  {2.0 * m * n * k / med / 1e9:8.1f} TF/s-equivalent")
+
+
 def bench_vit_attn(ctx, dtype=torch.bfloat16):
     import ctypes as C
     print("== vit attention ==")
@@ -105,7 +117,29 @@ if __name__ == "__main__":
     ctx = _lib.Context.get(0)
     if "gemm" in which:
         bench_gemm(ctx)
+    if "ablate" in which:
+        bench_gemm_ablate(ctx)
     if "attn" in which:
         bench_vit_attn(ctx)
     if "gemv" in which:
         bench_decode(ctx)
+
+
+def bench_gemm_pad(ctx, dtype=torch.bfloat16):
+    """Does a non-power-of-two leading dimension change the DMA-bound rate?  (L2 channel camping test)"""
+    print("== gemm leading-dimension padding test ==")
+    for (m, n, k, name) in ((102800, 3072, 1024, "vit qkv"), (102800, 4096, 1024, "vit fc1"), (102800, 1024, 4096, "vit fc2-shape"),
+                            (8192, 8192, 8192, "8192^3")):
+        for pad_a, pad_w in ((0, 0), (64, 0), (0, 64), (64, 64), (32, 32), (128, 128)):
+            abuf = torch.randn(m, k + pad_a, device=DEV).to(dtype)
+            wbuf = (torch.randn(n, k + pad_w, device=DEV) * 0.02).to(dtype)
+            a, w = abuf[:, :k], wbuf[:, :k]
+            bias = torch.randn(n, device=DEV)
+            out = torch.empty(m, n, device=DEV, dtype=dtype)
+            med, mn = timeit(lambda: ctx.gemm(a, w, bias, _lib.EPI_BIAS, out=out))
+            print(f"{name:14s} padA={pad_a:3d} padW={pad_w:3d}: {med:8.3f} / {mn:8.3f} ms  {2.0 * m * n * k / med / 1e9:8.1f} TF/s")
+            del abuf, wbuf, out
+
+
+if "pad" in sys.argv[1:]:
+    bench_gemm_pad(_lib.Context.get(0))
