@@ -16,12 +16,15 @@ int pgv_launch_rope_kv_write(int dtype, void* qkv, const int* row_b, const int* 
                              int heads, int max_seq, hipStream_t s);
 int pgv_launch_prefill_attn(pgv_ctx* ctx, int dtype, const void* qkv, void* out, const void* Kc, const void* Vc, const int* cu, int B, int max_len,
                             int H, int heads, int max_seq, double flops, hipStream_t s);
-int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void* x, int ldx, void* out, int ldo, int N, int K, int B, hipStream_t s);
+int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void* x, int ldx, void* out, int ldo, int N, int K, int B, hipStream_t s,
+                    int splits = 1);
+int pgv_launch_rms_resid(int dtype, float* resid, const float* part, int nparts, int B, const float* gamma, float eps, void* xn, int H, hipStream_t s);
 int pgv_launch_decode_attn(pgv_ctx* ctx, int dtype, const void* qkv, const int* pos, const void* rope, void* Kc, void* Vc, void* out, int B, int H,
                            int heads, int max_seq, double bytes, hipStream_t s);
 int pgv_launch_argmax(const float* logits, int V, int B, int* next, int* pos, int* step, int* hist, int hist_stride, int* done, int eos, int flags,
                       hipStream_t s);
-enum { GV_STORE16 = 0, GV_RESID = 1, GV_SWIGLU = 2, GV_F32 = 3 };
+enum { GV_STORE16 = 0, GV_RESID = 1, GV_SWIGLU = 2, GV_F32 = 3, GV_PART = 4 };
+constexpr int kSplits = 2;      // split-K of the residual GEMVs (o_proj, down_proj) in decode
 enum { AM_INC_POS = 1, AM_RECORD = 2 };
 
 constexpr int kMaxPos = 4096;   // max_position_embeddings of LLaVA-1.5 / Vicuna-1.5
@@ -53,7 +56,7 @@ struct pgv_kv {
     char* blob = nullptr;
     std::vector<void*> Kc, Vc;          // per layer [B][heads][max_seq][128]
     // fixed-address decode buffers (so a decode step can be captured into a hipGraph)
-    float* resid; void* xn; void* qkv; void* ao; void* act; float* logits;
+    float* resid; void* xn; void* qkv; void* ao; void* act; float* logits; float* part;
     int *d_pos, *d_cur, *d_step, *d_done, *d_hist;
     std::vector<int> h_len;
     std::vector<int> h_meta;           // staging for prefill row maps (kept alive across the async copy)
@@ -199,12 +202,12 @@ extern "C" int pgv_kv_create(pgv_ctx* ctx, pgv_llm* llm, int batch, int max_seq,
     auto take = [&](size_t bytes) { size_t o = off; off += pgv_align(bytes); return o; };
     const size_t o_cache = take(per * 2 * L);
     const size_t o_resid = take(B * H * 4), o_xn = take(B * H * 2), o_qkv = take(B * 3 * H * 2), o_ao = take(B * H * 2), o_act = take(B * I * 2),
-                 o_logits = take(B * V * 4), o_ints = take((4 * B + B * (size_t)max_seq) * 4);
+                 o_logits = take(B * V * 4), o_part = take((size_t)kSplits * B * H * 4), o_ints = take((4 * B + B * (size_t)max_seq) * 4);
     hipError_t e = hipMalloc((void**)&kv->blob, off);
     if (e != hipSuccess) { delete kv; pgv_set_error("pgv_kv_create: hipMalloc(%zu MiB): %s", off >> 20, hipGetErrorString(e)); return PGV_ENOMEM; }
     char* b = kv->blob;
     for (size_t i = 0; i < L; ++i) { kv->Kc.push_back(b + o_cache + per * 2 * i); kv->Vc.push_back(b + o_cache + per * (2 * i + 1)); }
-    kv->resid = (float*)(b + o_resid); kv->xn = b + o_xn; kv->qkv = b + o_qkv; kv->ao = b + o_ao; kv->act = b + o_act; kv->logits = (float*)(b + o_logits);
+    kv->resid = (float*)(b + o_resid); kv->xn = b + o_xn; kv->qkv = b + o_qkv; kv->ao = b + o_ao; kv->act = b + o_act; kv->logits = (float*)(b + o_logits); kv->part = (float*)(b + o_part);
     int* ints = (int*)(b + o_ints);
     kv->d_pos = ints; kv->d_cur = ints + B; kv->d_step = ints + 2 * B; kv->d_done = ints + 3 * B; kv->d_hist = ints + 4 * B;
     e = hipMemset(ints, 0, (4 * B + B * (size_t)max_seq) * 4);
@@ -226,9 +229,9 @@ extern "C" int pgv_kv_len(const pgv_kv* kv, int b) { return (kv && b >= 0 && b <
 // ---------------------------------------------------------------------------------------------
 // shared tail: final norm + lm_head + argmax on kv->resid [B,H]
 // ---------------------------------------------------------------------------------------------
-static int lm_head_and_pick(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int B, int eos, int flags, hipStream_t s) {
+static int lm_head_and_pick(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int B, int eos, int flags, hipStream_t s, int nparts = 0) {
     const int H = m->cfg.hidden, V = m->cfg.vocab;
-    PGV_TRY(pgv_launch_rmsnorm(m->dtype, kv->resid, m->norm_g, m->cfg.eps, kv->xn, B, H, s));
+    PGV_TRY(pgv_launch_rms_resid(m->dtype, kv->resid, kv->part, nparts, B, m->norm_g, m->cfg.eps, kv->xn, H, s));
     PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_F32, m->lm_head, kv->xn, H, kv->logits, V, V, H, B, s));
     PGV_TRY(pgv_launch_argmax(kv->logits, V, B, kv->d_cur, kv->d_pos, kv->d_step, kv->d_hist, kv->max_seq, kv->d_done, eos, flags, s));
     return PGV_OK;
@@ -327,15 +330,16 @@ static int decode_enqueue(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int eos, int fla
     for (int b = 0; b < B; ++b) kv_bytes += 2.0 * 2.0 * (double)(kv->h_len[b] + 1) * H;
     for (int li = 0; li < m->cfg.layers; ++li) {
         const LlmLayer& l = m->layers[li];
-        PGV_TRY(pgv_launch_rmsnorm(m->dtype, kv->resid, l.in_g, m->cfg.eps, kv->xn, B, H, s));
+        // input norm; for li > 0 it also folds the previous layer's down_proj split-K partials into the residual
+        PGV_TRY(pgv_launch_rms_resid(m->dtype, kv->resid, kv->part, li == 0 ? 0 : kSplits, B, l.in_g, m->cfg.eps, kv->xn, H, s));
         PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_STORE16, l.wqkv, kv->xn, H, kv->qkv, 3 * H, 3 * H, H, B, s));
         PGV_TRY(pgv_launch_decode_attn(ctx, m->dtype, kv->qkv, kv->d_pos, m->rope, kv->Kc[li], kv->Vc[li], kv->ao, B, H, heads, kv->max_seq, kv_bytes, s));
-        PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_RESID, l.wo, kv->ao, H, kv->resid, H, H, H, B, s));
-        PGV_TRY(pgv_launch_rmsnorm(m->dtype, kv->resid, l.post_g, m->cfg.eps, kv->xn, B, H, s));
+        PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_PART, l.wo, kv->ao, H, kv->part, H, H, H, B, s, kSplits));
+        PGV_TRY(pgv_launch_rms_resid(m->dtype, kv->resid, kv->part, kSplits, B, l.post_g, m->cfg.eps, kv->xn, H, s));
         PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_SWIGLU, l.wgu, kv->xn, H, kv->act, I, 2 * I, H, B, s));
-        PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_RESID, l.wdown, kv->act, I, kv->resid, H, H, I, B, s));
+        PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_PART, l.wdown, kv->act, I, kv->part, H, H, I, B, s, kSplits));
     }
-    PGV_TRY(lm_head_and_pick(ctx, m, kv, B, eos, flags, s));
+    PGV_TRY(lm_head_and_pick(ctx, m, kv, B, eos, flags, s, m->cfg.layers > 0 ? kSplits : 0));
     return PGV_OK;
 }
 

@@ -12,6 +12,16 @@ namespace {
 
 constexpr int HD = 128;   // LLaMA head_dim
 
+// sum over each aligned group of 16 lanes with DPP (VALU latency) instead of ds_bpermute shuffles (LDS crossbar latency):
+// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_ror:4, row_ror:8 -> every lane of the row ends up with the row total.
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
+    return v;
+}
+
 // ---------------------------------------------------------------------------------------------
 // embedding gather + video splice -> fp32 residual stream.  row_src[r] >= 0: token id; < 0: -(video row + 1)
 // ---------------------------------------------------------------------------------------------
@@ -244,11 +254,12 @@ __global__ __launch_bounds__(256) void prefill_attn_kernel(PrefillAttnArgs p) {
 // Workgroup = 8 waves, owns TILES row blocks; wave w takes k-steps w, w+8, ... (adjacent KiBs of the same row block).
 // B operand = x fragment (lane: batch l&15, k (l>>4)*8..+8) served by L2.  Partial 16x16 tiles are reduced through LDS.
 // ---------------------------------------------------------------------------------------------
-enum { GV_STORE16 = 0, GV_RESID = 1, GV_SWIGLU = 2, GV_F32 = 3 };
+enum { GV_STORE16 = 0, GV_RESID = 1, GV_SWIGLU = 2, GV_F32 = 3, GV_PART = 4 };
 
 struct GemvArgs {
     const char* W; const char* x; char* out;
     int N, K, B, ldx, ldo;
+    int kb_per;     // k-blocks (of 32) per split; gridDim.y splits write fp32 partials [split][B][ldo] in GV_PART mode
 };
 
 template <typename T, int MODE>
@@ -276,8 +287,9 @@ __global__ __launch_bounds__(512) void gemv_mfma_kernel(GemvArgs p) {
 #pragma unroll
     for (int t = 0; t < TILES; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     constexpr int U = (TILES == 2) ? 4 : 8;
-    int kk = w;
-    for (; kk + 8 * (U - 1) < kblocks; kk += 8 * U) {
+    const int kb_end = min(kblocks, (int)(blockIdx.y + 1) * p.kb_per);
+    int kk = blockIdx.y * p.kb_per + w;
+    for (; kk + 8 * (U - 1) < kb_end; kk += 8 * U) {
         typename T::v8 wf[U][TILES], xf[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -290,7 +302,7 @@ __global__ __launch_bounds__(512) void gemv_mfma_kernel(GemvArgs p) {
 #pragma unroll
             for (int t = 0; t < TILES; ++t) acc[t] = T::mfma16(wf[u][t], xf[u], acc[t]);
     }
-    for (; kk < kblocks; kk += 8) {
+    for (; kk < kb_end; kk += 8) {
         const typename T::v8 xf = *(const typename T::v8*)(xp + (size_t)kk * 64);
 #pragma unroll
         for (int t = 0; t < TILES; ++t) {
@@ -323,11 +335,62 @@ __global__ __launch_bounds__(512) void gemv_mfma_kernel(GemvArgs p) {
     } else if constexpr (MODE == GV_RESID) {
         f32x4_t* rp = (f32x4_t*)(p.out + ((size_t)b * p.ldo + n0) * 4);
         *rp = *rp + tot[0];
+    } else if constexpr (MODE == GV_PART) {
+        *(f32x4_t*)((float*)p.out + ((size_t)blockIdx.y * p.B + b) * p.ldo + n0) = tot[0];
     } else {
         float* op = (float*)p.out + (size_t)b * p.ldo + n0;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
             if (n0 + r < p.N) op[r] = tot[0][r];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// decode: residual update from split-K partials + RMSNorm in one launch (one workgroup per sequence):
+//   resid[b] += part[0][b] + part[1][b] + ...   (fixed order -> deterministic),   xn[b] = rmsnorm(resid[b]) * gamma
+// Every residual-accumulating decode GEMV (o_proj, down_proj) is followed by an RMSNorm, so the split-K combine rides
+// along for free and the GEMV can use gridDim.y splits to put >= 2 workgroups on every CU.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int NP>
+__global__ __launch_bounds__(256) void rms_resid_kernel(float* __restrict__ resid, const float* __restrict__ part, int B,
+                                                        const float* __restrict__ gamma, float eps, typename T::elem* __restrict__ xn, int H) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float* r = resid + (size_t)b * H;
+    constexpr int MAXV = 5;                              // H <= 5120
+    f32x4_t v[MAXV], g[MAXV], pp[MAXV][NP > 0 ? NP : 1];
+    // issue every load up front (one L2 round trip instead of three)
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 256 + tid) * 4;
+        if (c < H) {
+            v[i] = *(const f32x4_t*)(r + c);
+#pragma unroll
+            for (int s = 0; s < NP; ++s) pp[i][s] = *(const f32x4_t*)(part + ((size_t)s * B + b) * H + c);
+            g[i] = *(const f32x4_t*)(gamma + c);
+        }
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 256 + tid) * 4;
+        if (c < H) {
+#pragma unroll
+            for (int s = 0; s < NP; ++s) v[i] += pp[i][s];
+            if (NP > 0) *(f32x4_t*)(r + c) = v[i];
+            ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
+        }
+    }
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    const float tot = (red[0] + red[1]) + (red[2] + red[3]);
+    const float rstd = rsqrtf(tot / (float)H + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 256 + tid) * 4;
+        if (c < H)
+            *(u32x2_t*)((char*)xn + ((size_t)b * H + c) * 2) = pack4<T>(v[i][0] * rstd * g[i][0], v[i][1] * rstd * g[i][1], v[i][2] * rstd * g[i][2], v[i][3] * rstd * g[i][3]);
     }
 }
 
@@ -400,7 +463,7 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(const typename T::elem
             float s = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) s += qr[e] * (float)kf[u][e];
-            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+            s = row16_sum(s);
             if (key < n_keys) {
                 const float mn = fmaxf(m[u], s);
                 const float alpha = exp2f(m[u] - mn), pv = exp2f(s - mn);
@@ -513,22 +576,34 @@ int pgv_launch_prefill_attn(pgv_ctx* ctx, int dtype, const void* qkv, void* out,
     return PGV_OK;
 }
 
-int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void* x, int ldx, void* out, int ldo, int N, int K, int B, hipStream_t s) {
+int pgv_launch_rms_resid(int dtype, float* resid, const float* part, int nparts, int B, const float* gamma, float eps, void* xn, int H, hipStream_t s) {
+    PGV_CHECK(H % 4 == 0 && H <= 5120, "rms_resid: hidden %d unsupported", H);
+    if (nparts == 0) PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((rms_resid_kernel<T, 0>), dim3(B), dim3(256), 0, s, resid, part, B, gamma, eps, (typename T::elem*)xn, H));
+    else if (nparts == 2) PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((rms_resid_kernel<T, 2>), dim3(B), dim3(256), 0, s, resid, part, B, gamma, eps, (typename T::elem*)xn, H));
+    else { pgv_set_error("rms_resid: %d partials unsupported", nparts); return PGV_EINVAL; }
+    return PGV_OK;
+}
+
+int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void* x, int ldx, void* out, int ldo, int N, int K, int B, hipStream_t s,
+                    int splits) {
     PGV_CHECK(B >= 1 && B <= 16, "gemv: batch %d outside [1,16]", B);
     PGV_CHECK(K % 32 == 0, "gemv: K=%d must be a multiple of 32", K);
     GemvArgs a;
     a.W = (const char*)W; a.x = (const char*)x; a.out = (char*)out; a.N = N; a.K = K; a.B = B; a.ldx = ldx; a.ldo = ldo;
+    PGV_CHECK(splits >= 1 && (splits == 1 || mode == GV_PART), "gemv: split-K needs the partial-output mode");
+    a.kb_per = ((K / 32) + splits - 1) / splits;
     int grid;
     // W must be in the fragment-blocked layout with its row count padded to a multiple of 16 (zero rows)
     if (mode == GV_SWIGLU) { PGV_CHECK(N % 64 == 0, "gemv swiglu: N=%d must be a multiple of 64", N); grid = N / 32; }
     else { if (mode != GV_F32) PGV_CHECK(N % 16 == 0, "gemv: N=%d must be a multiple of 16", N); grid = (N + 15) / 16; }
     pgv_prof_begin(ctx, 3, s);
-#define PGV_GEMV(MODE_) PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gemv_mfma_kernel<T, MODE_>), dim3(grid), dim3(512), 0, s, a))
+#define PGV_GEMV(MODE_) PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gemv_mfma_kernel<T, MODE_>), dim3(grid, splits), dim3(512), 0, s, a))
     switch (mode) {
         case GV_STORE16: PGV_GEMV(GV_STORE16); break;
         case GV_RESID: PGV_GEMV(GV_RESID); break;
         case GV_SWIGLU: PGV_GEMV(GV_SWIGLU); break;
         case GV_F32: PGV_GEMV(GV_F32); break;
+        case GV_PART: PGV_GEMV(GV_PART); break;
         default: pgv_set_error("gemv: bad mode %d", mode); return PGV_EINVAL;
     }
 #undef PGV_GEMV
@@ -556,7 +631,8 @@ int pgv_launch_argmax(const float* logits, int V, int B, int* next, int* pos, in
 extern "C" int pgv_gemv(pgv_ctx* ctx, int dtype, int mode, const void* d_W, const void* d_x, int ldx, void* d_out, int ldo, int N, int K, int B,
                         void* stream) {
     PGV_CHECK(ctx && d_W && d_x && d_out, "pgv_gemv: null argument");
-    return pgv_launch_gemv(ctx, dtype, mode, d_W, d_x, ldx, d_out, ldo, N, K, B, (hipStream_t)stream);
+    PGV_CHECK(mode >= 0 && mode <= 3, "pgv_gemv: mode %d outside [0,3]", mode);
+    return pgv_launch_gemv(ctx, dtype, mode, d_W, d_x, ldx, d_out, ldo, N, K, B, (hipStream_t)stream, 1);
 }
 
 #include "weights.h"
