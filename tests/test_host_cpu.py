@@ -137,7 +137,7 @@ def infer(group):
     toks = torch.stack([torch.arange(NEW, dtype=torch.int32) + 100 * i for i in group])
     return toks, [NEW - (i % 3) for i in group]
 ans = parallel.run_sharded(N, infer, NEW, rank, world, torch.device("cpu"), per_gpu_batch=1)
-print("RESULT", rank, json.dumps(ans))
+open({str(tmp_path)!r} + f"/result_{{rank}}.json", "w").write(json.dumps(ans))   # files, not stdout: rank lines interleave
 torch.distributed.destroy_process_group()
 ''')
     port = _free_port()
@@ -145,11 +145,7 @@ torch.distributed.destroy_process_group()
            "--master-port", str(port), str(script)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
-    results = {}
-    for line in r.stdout.splitlines():
-        if line.startswith("RESULT"):
-            _, rk, js = line.split(" ", 2)
-            results[int(rk)] = json.loads(js)
+    results = {rk: json.load(open(tmp_path / f"result_{rk}.json")) for rk in (0, 1) if (tmp_path / f"result_{rk}.json").exists()}
     assert set(results) == {0, 1} and results[0] == results[1]
     ans = results[0]
     want = [[100 * i + t for t in range(6 - (i % 3))] for i in range(5)]
