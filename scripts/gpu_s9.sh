@@ -1,0 +1,9 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out/s9
+PGV_GEMM_CFG=6 timeout 600 python -m pytest tests/test_gpu_vision.py -x -q -k "gemm" > gpurun_out/s9/pytest_gemm_cfg6.log 2>&1
+tail -5 gpurun_out/s9/pytest_gemm_cfg6.log
+PGV_GEMM_CFG=6 timeout 300 python scripts/microbench.py gemm > gpurun_out/s9/gemm_cfg6.log 2>&1
+for abl in 1 3 4 6; do
+  PGV_GEMM_CFG=6 PGV_GEMM_ABLATE=$abl timeout 200 python scripts/microbench.py ablate > gpurun_out/s9/ablate_$abl.log 2>&1
+done

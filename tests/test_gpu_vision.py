@@ -78,6 +78,34 @@ def test_gemm_activation_epilogues(ctx, dtype):
     assert out.shape == (M, I) and rel(out, ref) < tol
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(4400, 4352, 64), (4609, 4104, 192), (9000, 2304, 320), (70000, 1024, 128)])
+def test_gemm_many_tiles(ctx, dtype, M, N, K):
+    """More output tiles than CUs (a persistent workgroup walks several tiles; K-steps 1, 3, 5, 2 per tile), ragged M and N
+    edges, every store shape (16-bit, fp32, fp32 read-modify-write).  Reference: torch fp32 on the same device."""
+    from video_llava_amd import _lib
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g, device=DEV).to(dtype)
+    w = (torch.randn(N, K, generator=g, device=DEV) * 0.1).to(dtype)
+    b = torch.randn(N, generator=g, device=DEV)
+    ref = a.float() @ w.float().t() + b
+    tol = 1.5e-3 if dtype == torch.float16 else 8e-3
+    out = ctx.gemm(a, w, b, _lib.EPI_BIAS)
+    assert rel(out, ref) < tol
+    err = (out.float() - ref).abs()
+    assert float(err.max()) < 0.05 * float(ref.abs().max()), f"worst element at {np.unravel_index(int(err.argmax()), err.shape)}"
+    r0 = torch.randn(M, N, generator=g, device=DEV)
+    r = r0.clone()
+    ctx.gemm(a, w, b, _lib.EPI_BIAS_RESID, out=r)
+    assert float((r - (r0 + ref)).abs().max()) < 1e-3
+    out32 = ctx.gemm(a, w, None, _lib.EPI_F32)
+    assert float((out32 - (ref - b)).abs().max()) < 1e-3
+    # rows beyond M / columns beyond N of a padded output buffer must stay untouched
+    pad = torch.full((M + 3, N + 8), 7.0, dtype=dtype, device=DEV)
+    ctx.gemm(a, w, b, _lib.EPI_BIAS, out=pad[:M, :N])
+    assert bool((pad[M:] == 7).all()) and bool((pad[:, N:] == 7).all()) and rel(pad[:M, :N], ref) < tol
+
+
 def test_gemm_rejects_bad_shapes(ctx):
     a = torch.zeros(4, 60, dtype=torch.float16, device=DEV)
     w = torch.zeros(8, 60, dtype=torch.float16, device=DEV)

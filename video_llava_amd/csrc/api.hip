@@ -31,6 +31,12 @@ extern "C" int pgv_ctx_create(int device, pgv_ctx** out) {
     pgv_ctx* c = new pgv_ctx();
     c->device = device;
     c->num_cu = prop.multiProcessorCount;
+    if (hipMalloc((void**)&c->zero_bias, PGV_ZERO_BIAS_LEN * sizeof(float)) != hipSuccess ||
+        hipMemset(c->zero_bias, 0, PGV_ZERO_BIAS_LEN * sizeof(float)) != hipSuccess) {
+        pgv_set_error("pgv_ctx_create: cannot allocate the zero-bias vector");
+        delete c;
+        return PGV_ENOMEM;
+    }
     *out = c;
     return PGV_OK;
 }
@@ -38,6 +44,7 @@ extern "C" int pgv_ctx_create(int device, pgv_ctx** out) {
 extern "C" void pgv_ctx_destroy(pgv_ctx* ctx) {
     if (!ctx) return;
     if (ctx->ws) (void)hipFree(ctx->ws);
+    if (ctx->zero_bias) (void)hipFree(ctx->zero_bias);
     if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
     for (auto& f : ctx->fam)
         for (auto e : f.ev) (void)hipEventDestroy(e);

@@ -46,6 +46,8 @@ struct pgv_prof_family {
     int64_t launches = 0;
 };
 
+constexpr int PGV_ZERO_BIAS_LEN = 1 << 16;
+
 struct pgv_ctx {
     int device = 0;
     int num_cu = 256;
@@ -55,6 +57,7 @@ struct pgv_ctx {
     bool prof = false;
     pgv_prof_family fam[PGV_NFAMILY];
     hipStream_t cap_stream = nullptr;   // used only to capture decode graphs
+    float* zero_bias = nullptr;         // PGV_ZERO_BIAS_LEN zeros: stands in for a null bias so the persistent GEMM epilogue is branch-free
 };
 
 // Reserve the arena for a call (may hipMalloc: never call inside graph capture).
