@@ -143,3 +143,27 @@ def bench_gemm_pad(ctx, dtype=torch.bfloat16):
 
 if "pad" in sys.argv[1:]:
     bench_gemm_pad(_lib.Context.get(0))
+
+
+def bench_gemm_data(ctx, dtype=torch.bfloat16):
+    """DVFS check: the same GEMM on zeros / small integers / random data (MI355X clocks to its power budget)."""
+    print("== gemm data-dependence (8192^3 and vit qkv) ==")
+    for (m, n, k, name) in ((8192, 8192, 8192, "8192^3"), (102800, 3072, 1024, "vit qkv")):
+        for fill in ("zeros", "ones", "randn", "uniform"):
+            if fill == "zeros":
+                a = torch.zeros(m, k, device=DEV, dtype=dtype); w = torch.zeros(n, k, device=DEV, dtype=dtype)
+            elif fill == "ones":
+                a = torch.ones(m, k, device=DEV, dtype=dtype); w = torch.ones(n, k, device=DEV, dtype=dtype)
+            elif fill == "randn":
+                a = torch.randn(m, k, device=DEV).to(dtype); w = (torch.randn(n, k, device=DEV) * 0.02).to(dtype)
+            else:
+                a = (torch.rand(m, k, device=DEV) * 2 - 1).to(dtype); w = (torch.rand(n, k, device=DEV) * 2 - 1).to(dtype)
+            bias = torch.zeros(n, device=DEV)
+            out = torch.empty(m, n, device=DEV, dtype=dtype)
+            med, mn = timeit(lambda: ctx.gemm(a, w, bias, _lib.EPI_BIAS, out=out))
+            print(f"{name:10s} {fill:8s}: {med:8.3f} / {mn:8.3f} ms  {2.0 * m * n * k / med / 1e9:8.1f} TF/s")
+            del a, w, out
+
+
+if "data" in sys.argv[1:]:
+    bench_gemm_data(_lib.Context.get(0))

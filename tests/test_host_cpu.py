@@ -151,3 +151,36 @@ torch.distributed.destroy_process_group()
     want = [[100 * i + t for t in range(6 - (i % 3))] for i in range(5)]
     want[3] = []                                                        # failed clip keeps an empty slot
     assert ans == want
+
+
+def test_no_kernel_spills_to_scratch():
+    """Every gfx950 kernel of libpgv must fit its registers: a spilled accumulator or DMA offset inside a GEMM/attention loop
+    costs 2-3x (seen while building the 4-wave GEMM), so scratch use is a build failure, not a perf note."""
+    from video_llava_amd import build
+    build.build()
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not all(os.path.exists(os.path.join(llvm, t)) for t in ("clang-offload-bundler", "llvm-readelf", "llvm-objcopy")):
+        pytest.skip("ROCm llvm tools not present")
+    import tempfile
+    checked = 0
+    bad = []
+    with tempfile.TemporaryDirectory() as td:
+        for src in build.sources_present():
+            obj = os.path.join(build.OBJ, src.replace(".hip", ".o"))
+            fat, co = os.path.join(td, "x.fatbin"), os.path.join(td, "x.co")
+            subprocess.run([f"{llvm}/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", obj, fat], check=True)
+            if not os.path.exists(fat) or os.path.getsize(fat) == 0:
+                continue                                    # host-only translation unit
+            r = subprocess.run([f"{llvm}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}",
+                                "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], capture_output=True, text=True)
+            assert r.returncode == 0, f"{src}: {r.stderr}"
+            notes = subprocess.run([f"{llvm}/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
+            names = re.findall(r"\.name:\s+(\S+)", notes)
+            segs = [int(x) for x in re.findall(r"\.private_segment_fixed_size:\s+(\d+)", notes)]
+            spills = [int(x) for x in re.findall(r"\.vgpr_spill_count:\s+(\d+)", notes)]
+            assert len(names) == len(segs) == len(spills), src
+            checked += len(names)
+            bad += [(n, sg, v) for n, sg, v in zip(names, segs, spills) if v > 0]
+            os.remove(fat)
+    assert checked >= 20, f"only {checked} kernels found"
+    assert not bad, f"kernels spilling VGPRs: {bad[:6]}"
