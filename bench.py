@@ -63,6 +63,31 @@ def make_prompts(n, vocab, video_rows, seed):
     return out
 
 
+PMC_PREFIX = {"gemm": "gemm_w4", "vit_attn": "vit_attn_kernel", "llm_prefill_attn": "prefill_attn_kernel",
+              "decode_gemv": "gemv_mfma_kernel", "decode_attn": "decode_attn_kernel"}
+
+
+def pmc_traffic(family):
+    """HBM-side traffic per launch of a kernel family from the committed rocprofv3 PMC passes (scripts/pmc_traffic.sh ->
+    scripts/pmc_summary.py -> profiles/*pmc_traffic.json): FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE,
+    call-weighted over the family's kernels.  rocprofv3 cannot wrap the process that is being timed, so the counters come from
+    a separate run of the same bench command with 9 decode tokens; null when no profile file is present."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    if not files or family not in PMC_PREFIX:
+        return {"traffic": None}
+    d = json.load(open(files[-1]))["kernels"]
+    calls = tot = 0.0
+    for name, r in d.items():
+        if name.startswith(PMC_PREFIX[family]) and r.get("fetch_bytes_corrected_x2") is not None:
+            calls += r["calls"]
+            tot += r["calls"] * (r["fetch_bytes_corrected_x2"] + (r.get("write_bytes_raw") or 0.0))
+    if calls == 0:
+        return {"traffic": None}
+    return {"traffic": tot / calls, "traffic_unit": "bytes/launch (FETCH_SIZE x2 + WRITE_SIZE, L2-miss side; Infinity-Cache hits are counted)",
+            "traffic_source": os.path.relpath(files[-1], ROOT)}
+
+
 def cpu_baseline(args, clips_per_step_tokens):
     """Time the CPU oracle (oracle/, a torch-fp32 restatement of the reference path) on a bounded sample and scale it to
     one clip: ViT on `cpu_frames` frames (23 layers), decoder prefill + 4 decode steps on `cpu_layers` layers."""
@@ -231,6 +256,8 @@ def main():
                         "frac": d["gbs"] / PEAK_HBM_GBS, "traffic": None}
         roofline["avg_launch_us"] = d["avg_us"]
         roofline["share_of_step"] = d["ms_per_step_est"] / ms_per_step
+        roofline["algorithmic_bytes_per_launch"] = raw[dom]["bytes"] / raw[dom]["launches"] if raw[dom]["bytes"] > 0 else None
+        roofline.update(pmc_traffic(dom))
 
     if rank == 0:
         line = {
