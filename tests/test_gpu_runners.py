@@ -1,0 +1,133 @@
+"""GPU end-to-end: the offline feature-extraction loop (reference scripts/save_spatio_temporal_clip_features.py) and the
+ActivityNet-QA runner (reference video_chatgpt/eval/run_inference_qa_activitynet.py) on synthetic .npy clips, checked against
+the CPU oracle: pooled features <= 1e-3 (fp16), answers token-exact for greedy decoding."""
+import json
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import llm as ollm
+from oracle import synth
+from oracle import vision as ovis
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _tower(ccfg, cw, dtype=torch.float16):
+    from video_llava_amd.vision_tower import CLIPVisionTower, CLIPVisionTowerConfig
+    t = CLIPVisionTower(CLIPVisionTowerConfig(hidden_size=ccfg.hidden, intermediate_size=ccfg.inter, num_hidden_layers=ccfg.layers,
+                                              num_attention_heads=ccfg.heads, image_size=ccfg.image, patch_size=ccfg.patch), dtype)
+    t.load_state_dict(cw)
+    return t
+
+
+def test_extraction_loop_writes_reference_format(ctx, tmp_path):
+    from video_llava_amd import feature_extraction as fx
+    ccfg = synth.CLIP_TINY
+    cw = synth.make_clip_weights(ccfg, seed=11)
+    tower = _tower(ccfg, cw)
+    vd, od = tmp_path / "videos", tmp_path / "feats"
+    vd.mkdir()
+    clips = {"vid_a": synth.make_frames(9, ccfg.image, seed=1), "vid_b": synth.make_frames(120, 20, seed=2)}     # b: 120 frames, needs sampling + resize
+    for k, v in clips.items():
+        np.save(vd / f"{k}.npy", v)
+    args = fx.parse_args(["--llava", "1.1", "--video_dir_path", str(vd), "--clip_feat_path", str(od)])
+    orig = dict(fx.LLAVA_VERSIONS)
+    fx.LLAVA_VERSIONS["1.1"] = ("tiny", (ccfg.image, ccfg.image))
+    try:
+        assert fx.run(args, vision_tower=tower) == 2
+        assert fx.run(args, vision_tower=tower) == 0                     # second run: everything already on disk
+    finally:
+        fx.LLAVA_VERSIONS.update(orig)
+    P = (ccfg.image // ccfg.patch) ** 2
+    for k in clips:
+        got = pickle.load(open(od / f"{k}.pkl", "rb"))
+        assert isinstance(got, np.ndarray) and got.dtype == np.float16 and got.shape == (100 + P, 1024)
+        frames = fx.load_video(str(vd / f"{k}.npy"), shape=(ccfg.image, ccfg.image))
+        ref = ovis.spatio_temporal_pool_numpy(ovis.clip_select_features(ovis.clip_preprocess(frames), cw, ccfg).numpy().astype(np.float16))
+        err = np.linalg.norm(got.astype(np.float64) - ref.astype(np.float64)) / np.linalg.norm(ref.astype(np.float64))
+        assert err < 1e-3, (k, err)
+        T = frames.shape[0]
+        assert not got[T:100].any()
+
+
+class _Tok:
+    """Synthetic tokenizer exposing exactly the calls the path makes: ids are byte values + 3, the three video tokens
+    sit at the top of the vocabulary."""
+
+    def __init__(self, vocab):
+        self.vocab = vocab
+        self.special = {"<vid_patch>": vocab - 3, "<vid_start>": vocab - 2, "<vid_end>": vocab - 1}
+
+    def _encode(self, s):
+        ids, i = [1], 0
+        while i < len(s):
+            for name, tid in self.special.items():
+                if s.startswith(name, i):
+                    ids.append(tid); i += len(name)
+                    break
+            else:
+                ids.append(3 + (ord(s[i]) % (self.vocab - 8))); i += 1
+        return ids
+
+    def __call__(self, x):
+        class R: pass
+        r = R()
+        r.input_ids = [self._encode(t) for t in x] if isinstance(x, (list, tuple)) else self._encode(x)
+        return r
+
+    def batch_decode(self, ids, skip_special_tokens=True):
+        return [" ".join(str(int(t)) for t in row) for row in ids]
+
+
+def test_qa_runner_end_to_end_matches_oracle(ctx, tmp_path):
+    from video_llava_amd.eval import run_inference_qa_activitynet as qa
+    from video_llava_amd.inference import build_prompt
+    from video_llava_amd.model.video_chatgpt import VideoChatGPTConfig, VideoChatGPTLlamaForCausalLM, VisionConfig
+    ccfg, lcfg = synth.CLIP_TINY, synth.LLAMA_TINY
+    cw = synth.make_clip_weights(ccfg, seed=21)
+    lw = synth.make_llama_weights(lcfg, seed=22, head_std=0.08)
+    tower = _tower(ccfg, cw)
+    model = VideoChatGPTLlamaForCausalLM(VideoChatGPTConfig(vocab_size=lcfg.vocab, hidden_size=lcfg.hidden, intermediate_size=lcfg.inter,
+                                                            num_hidden_layers=lcfg.layers, num_attention_heads=lcfg.heads, eos_token_id=None,
+                                                            max_position_embeddings=2048),
+                                         VisionConfig(frame_size=ccfg.image), torch.float16)
+    model.load_state_dict(lw)
+    vc = model.get_model().vision_config
+    vc.vid_patch_token, vc.vid_start_token, vc.vid_end_token, vc.use_vid_start_end = lcfg.vocab - 3, lcfg.vocab - 2, lcfg.vocab - 1, True
+    tok = _Tok(lcfg.vocab)
+
+    class IP:
+        crop_size = {"height": ccfg.image, "width": ccfg.image}
+    P = (ccfg.image // ccfg.patch) ** 2
+    V = 100 + P
+    vd = tmp_path / "v"; vd.mkdir()
+    names = ["k1", "k2", "k3"]
+    for i, n in enumerate(names):
+        np.save(vd / f"v_{n}.npy", synth.make_frames(5 + i, ccfg.image, seed=30 + i))
+    qs = [{"video_name": n, "question": f"what happens {i}?", "question_id": f"{n}_q"} for i, n in enumerate(names)]
+    qs.insert(2, {"video_name": "missing", "question": "gone?", "question_id": "missing_q"})
+    ans = [{"answer": f"a{i}"} for i in range(len(qs))]
+    (tmp_path / "q.json").write_text(json.dumps(qs)); (tmp_path / "a.json").write_text(json.dumps(ans))
+    NEW = 6
+    args = qa.parse_args(["--video_dir", str(vd), "--gt_file_question", str(tmp_path / "q.json"), "--gt_file_answers", str(tmp_path / "a.json"),
+                          "--output_dir", str(tmp_path / "out"), "--output_name", "preds", "--model-name", "x", "--projection_path", "y",
+                          "--batch", "2", "--max_new_tokens", str(NEW)])
+    out = qa.run_inference(args, components=(model, tower, tok, IP(), V))
+    on_disk = json.load(open(tmp_path / "out" / "preds.json"))
+    assert on_disk == out and [o["id"] for o in out] == ["k1_q", "k2_q", "k3_q"]          # the missing video is left out, order kept
+    assert all(set(o) == {"id", "question", "answer", "pred"} for o in out)
+    # oracle: same frames -> pooled features -> greedy tokens
+    for o, n in zip(out, names):
+        frames = np.load(vd / f"v_{n}.npy")
+        pooled = ovis.spatio_temporal_pool_torch(ovis.clip_select_features(ovis.clip_preprocess(frames), cw, ccfg))
+        prompt, _ = build_prompt(o["question"], "pg-video-llava", V, True)
+        ids = tok([prompt]).input_ids[0]
+        ref, margins = ollm.greedy_generate(lw, lcfg, ids, pooled.float(), lcfg.vocab - 2, lcfg.vocab - 1, lcfg.vocab - 3, NEW, return_margins=True)
+        got = [int(t) for t in o["pred"].split()]
+        k = next((i for i, m in enumerate(margins) if m < 0.02), NEW)           # compare up to the first near-tie of the oracle
+        assert got[:k] == ref[:k], (n, got, ref, margins)

@@ -184,3 +184,86 @@ def test_no_kernel_spills_to_scratch():
             os.remove(fat)
     assert checked >= 20, f"only {checked} kernels found"
     assert not bad, f"kernels spilling VGPRs: {bad[:6]}"
+
+
+# --------------------------------------------------------------------------------------------------
+# offline feature extraction (scripts/save_spatio_temporal_clip_features.py) and the QA runner: host logic
+# --------------------------------------------------------------------------------------------------
+def test_extraction_cli_and_numpy_twin(tmp_path, golden_dir):
+    from video_llava_amd import feature_extraction as fx
+    a = fx.parse_args(["--llava", "1.5", "--video_dir_path", "v", "--clip_feat_path", "o"])
+    assert a.infer_batch == 32 and fx.LLAVA_VERSIONS[a.llava][1] == (336, 336)
+    with pytest.raises(SystemExit):
+        fx.parse_args(["--llava", "2.0", "--video_dir_path", "v", "--clip_feat_path", "o"])
+    # numpy twin == the golden produced by the reference's own function
+    g = np.load(os.path.join(golden_dir, "pool.npz"))                      # outputs of the reference script's own function
+    for name, (T, P) in {"t8_p16": (8, 16), "t100_p16": (100, 16), "t3_p4": (3, 4)}.items():
+        rng = np.random.default_rng(int(g[name + "_seed"]))
+        f16 = (rng.standard_normal((T, P, 1024), dtype=np.float32) * 1.5).astype(np.float16)
+        assert np.array_equal(fx.get_spatio_temporal_features(f16), g[name + "_numpy"])
+    x = np.random.default_rng(0).standard_normal((7, 16, 1024)).astype(np.float16)
+    y = fx.get_spatio_temporal_features(x)
+    assert y.dtype == np.float16 and y.shape == (116, 1024) and not y[7:100].any()
+    assert np.array_equal(y[:7], np.mean(x, axis=1)) and np.array_equal(y[100:], np.mean(x, axis=0))
+
+
+def test_extraction_load_video_npy_sampling_and_resize(tmp_path):
+    from video_llava_amd import feature_extraction as fx
+    rng = np.random.default_rng(1)
+    clip = rng.integers(0, 256, (130, 60, 80, 3), dtype=np.uint8)
+    p = tmp_path / "clip.npy"
+    np.save(p, clip)
+    out = fx.load_video(str(p), num_frm=100, shape=(224, 224))
+    assert out.shape == (100, 224, 224, 3) and out.dtype == np.uint8
+    idx = fx.get_seq_frames(130, 100)
+    ref = torch.nn.functional.interpolate(torch.from_numpy(clip[idx]).permute(0, 3, 1, 2).float(), size=(224, 224))
+    assert np.array_equal(out, ref.permute(0, 2, 3, 1).to(torch.uint8).numpy())          # the reference's nearest resize
+    short = fx.load_video(str(p), num_frm=200, shape=(60, 80))
+    assert short.shape == (130, 60, 80, 3) and np.array_equal(short, clip[fx.get_seq_frames(130, 130)])
+
+
+def test_extraction_loop_skips_flushes_and_survives_failures(tmp_path):
+    """run(): idempotent skip of existing .pkl, periodic flush, a broken clip is reported and skipped; pkl = np.float16 array."""
+    import pickle
+    from video_llava_amd import feature_extraction as fx
+    vd, od = tmp_path / "videos", tmp_path / "feats"
+    vd.mkdir(); od.mkdir()
+    for name in ("a.npy", "b.npy", "c.npy", "bad.npy"):
+        np.save(vd / name, np.zeros((3, 8, 8, 3), np.uint8))
+    (vd / "bad.npy").write_bytes(b"not a numpy file")
+    with open(od / "a.pkl", "wb") as f:
+        pickle.dump(np.ones((2, 2), np.float16), f)
+    calls = []
+    orig = fx.extract_clip_features
+    fx.extract_clip_features = lambda path, tower, size: (calls.append(os.path.basename(path)), np.load(path),
+                                                          np.full((356, 1024), len(calls), np.float16))[2]
+    try:
+        logs = []
+        args = fx.parse_args(["--llava", "1.1", "--video_dir_path", str(vd), "--clip_feat_path", str(od)])
+        n = fx.run(args, vision_tower=object(), save_every=2, log=logs.append)
+    finally:
+        fx.extract_clip_features = orig
+    assert n == 2 and calls == ["b.npy", "bad.npy", "c.npy"] and len(logs) == 1 and "bad.npy" in logs[0]
+    assert pickle.load(open(od / "a.pkl", "rb")).shape == (2, 2)                        # untouched
+    for key in ("b", "c"):
+        arr = pickle.load(open(od / f"{key}.pkl", "rb"))
+        assert isinstance(arr, np.ndarray) and arr.dtype == np.float16 and arr.shape == (356, 1024)
+    assert not (od / "bad.pkl").exists()
+
+
+def test_qa_runner_host_logic(tmp_path):
+    from video_llava_amd.eval import run_inference_qa_activitynet as qa
+    a = qa.parse_args(["--video_dir", "v", "--gt_file_question", "q", "--gt_file_answers", "a", "--output_dir", "o", "--output_name", "n",
+                       "--model-name", "m", "--projection_path", "p"])
+    assert a.conv_mode == "pg-video-llava" and not a.use_asr
+    vd = tmp_path / "v"; vd.mkdir()
+    (vd / "v_x1.mov").write_bytes(b""); (vd / "v_x1.mkv").write_bytes(b""); (vd / "v_y.npy").write_bytes(b"")
+    assert qa.find_video(str(vd), "x1").endswith("v_x1.mov")           # reference order: mp4, avi, mov, mkv
+    assert qa.find_video(str(vd), "y").endswith("v_y.npy") and qa.find_video(str(vd), "zz") is None
+    q = [{"video_name": "x1", "question": "what?", "question_id": "x1_0"}, {"video_name": "zz", "question": "why?", "question_id": "zz_0"}]
+    an = [{"answer": "yes"}, {"answer": "no"}]
+    (tmp_path / "q.json").write_text(json.dumps(q)); (tmp_path / "a.json").write_text(json.dumps(an))
+    samples = qa.load_samples(str(tmp_path / "q.json"), str(tmp_path / "a.json"))
+    assert samples[1] == {"video_name": "zz", "question": "why?", "id": "zz_0", "answer": "no"}
+    out = qa.build_output(samples, ["a dog", None])
+    assert out == [{"id": "x1_0", "question": "what?", "answer": "yes", "pred": "a dog"}]

@@ -447,33 +447,40 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(const typename T::elem
         for (int e = 0; e < 8; ++e) o[u][e] = 0.f;
     const int n_keys = pos + 1;
     const int key0 = w * 4 + slot;
-    typename T::v8 kf[2], vf[2], kn[2], vn[2];
+    // DEPTH rounds of 64 keys are kept in flight per workgroup (DEPTH x 4 x 16-B loads per lane): with one workgroup per CU and a
+    // ~2 us loaded HBM latency, two rounds (32 KiB per CU) sustain only ~3.5 TB/s over the chip; four rounds double that.
+    constexpr int DEPTH = 4;
+    typename T::v8 kq[DEPTH][2], vq[DEPTH][2];
     auto load = [&](int key, typename T::v8& kk_, typename T::v8& vv_) {
         const int kc = min(key, n_keys - 1);               // clamped rows are masked below
         kk_ = *(const typename T::v8*)(kcache + (size_t)kc * HD + dc * 8);
         vv_ = *(const typename T::v8*)(vcache + (size_t)kc * HD + dc * 8);
     };
-    load(key0, kf[0], vf[0]);
-    load(key0 + 32, kf[1], vf[1]);
-    for (int base = key0; base < n_keys; base += 64) {
-        if (base + 64 < n_keys) { load(base + 64, kn[0], vn[0]); load(base + 96, kn[1], vn[1]); }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int key = base + 32 * u;
-            float s = 0.f;
+    for (int d = 0; d < DEPTH; ++d) { load(key0 + 64 * d, kq[d][0], vq[d][0]); load(key0 + 64 * d + 32, kq[d][1], vq[d][1]); }
+    for (int base = key0; base < n_keys; base += 64 * DEPTH) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) s += qr[e] * (float)kf[u][e];
-            s = row16_sum(s);
-            if (key < n_keys) {
-                const float mn = fmaxf(m[u], s);
-                const float alpha = exp2f(m[u] - mn), pv = exp2f(s - mn);
-                m[u] = mn;
-                l[u] = l[u] * alpha + pv;
+        for (int d = 0; d < DEPTH; ++d) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[u][e] = o[u][e] * alpha + pv * (float)vf[u][e];
+            for (int u = 0; u < 2; ++u) {
+                const int key = base + 64 * d + 32 * u;
+                float s = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += qr[e] * (float)kq[d][u][e];
+                s = row16_sum(s);
+                if (key < n_keys) {
+                    const float mn = fmaxf(m[u], s);
+                    const float alpha = exp2f(m[u] - mn), pv = exp2f(s - mn);
+                    m[u] = mn;
+                    l[u] = l[u] * alpha + pv;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[u][e] = o[u][e] * alpha + pv * (float)vq[d][u][e];
+                }
             }
+            // refill this ring slot with the round DEPTH ahead (clamped loads past the end are harmless and masked)
+            load(base + 64 * (d + DEPTH), kq[d][0], vq[d][0]);
+            load(base + 64 * (d + DEPTH) + 32, kq[d][1], vq[d][1]);
         }
-        kf[0] = kn[0]; vf[0] = vn[0]; kf[1] = kn[1]; vf[1] = vn[1];
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {

@@ -1,0 +1,135 @@
+"""Offline CLIP feature extraction with the reference script's functions, CLI and on-disk format
+(scripts/save_spatio_temporal_clip_features.py: `load_video` :13-32, `get_seq_frames` :35-43,
+`get_spatio_temporal_features` :46-57, `parse_args` :60-71, `main` :74-139).
+
+Per video it writes `{clip_feat_path}/{video_id}.pkl` = pickle(np.float16[100 + P, 1024]) -- the file the reference's
+training loader opens (video_chatgpt/train/train.py:404-405).  Device work (preprocess, CLIP tower, pooling) runs in libpgv;
+this module is the host loop: directory walk, idempotent skip, decode, periodic flush.
+
+Differences that do not change the bytes written:
+  * `--infer_batch` is accepted for drop-in compatibility; the tower processes all sampled frames of a clip in one call
+    because its result is bit-identical for every split (tests/test_gpu_vision.py::test_vit_100_frames_properties), and the
+    105 MB fp32 D2H copy per clip of the reference's batching loop (:108-121) disappears (features stay on the device until
+    the 0.73 MB pooled result).
+  * frames may also come from `<name>.npy` files (uint8 [T, H, W, 3]) -- `decord` is not installable offline here.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import pickle
+
+import numpy as np
+import torch
+
+from .eval.model_utils import get_seq_frames  # noqa: F401  (re-exported: the reference script defines its own copy)
+
+LLAVA_VERSIONS = {"1.1": ("openai/clip-vit-large-patch14", (224, 224)), "1.5": ("openai/clip-vit-large-patch14-336", (336, 336))}
+VIDEO_EXTENSIONS_NPY = (".npy",)
+
+
+def load_video(vis_path, num_frm=100, shape=(224, 224)):
+    """Up to `num_frm` uniformly sampled frames as a uint8 array [k, h, w, 3]: nearest-neighbour resize to `shape` without aspect
+    preservation, exactly the arithmetic of the reference (:13-32; F.interpolate default mode on the float tensor, cast back to
+    uint8).  The reference returns PIL images only to feed CLIPImageProcessor; the HIP preprocessing takes the array directly."""
+    if str(vis_path).endswith(VIDEO_EXTENSIONS_NPY):
+        src = np.load(vis_path, mmap_mode="r")
+        if src.dtype != np.uint8 or src.ndim != 4 or src.shape[-1] != 3:
+            raise ValueError(f"{vis_path}: expected uint8 [T, H, W, 3], got {src.dtype} {src.shape}")
+        total = src.shape[0]
+        k = min(total, num_frm)
+        arr = np.ascontiguousarray(src[get_seq_frames(total, k)])
+    else:
+        try:
+            from decord import VideoReader, cpu
+        except ImportError as e:
+            raise RuntimeError("load_video needs the `decord` package to decode video files (or pass .npy frame arrays)") from e
+        vr = VideoReader(vis_path, ctx=cpu(0))
+        total = len(vr)
+        k = min(total, num_frm)
+        arr = vr.get_batch(get_seq_frames(total, k)).asnumpy()
+    h, w = shape
+    if arr.shape[-3] != h or arr.shape[-2] != w:
+        t = torch.from_numpy(arr).permute(0, 3, 1, 2).float()
+        t = torch.nn.functional.interpolate(t, size=(h, w))
+        arr = t.permute(0, 2, 3, 1).to(torch.uint8).numpy()
+    return arr
+
+
+def get_spatio_temporal_features(features, num_temporal_tokens=100):
+    """[t, s, c] -> np.float16 [num_temporal_tokens + s, c] (reference :46-57: np.mean over patches, zero padding to 100 rows,
+    np.mean over frames, concatenate).  A device tensor is pooled by the HIP kernel (fp32 accumulation, one pass); a numpy array
+    takes the reference's numpy arithmetic unchanged."""
+    if isinstance(features, np.ndarray):
+        t = features.shape[0]
+        temporal = np.mean(features, axis=1)
+        if num_temporal_tokens - t > 0:
+            temporal = np.pad(temporal, ((0, num_temporal_tokens - t), (0, 0)), mode="constant")
+        return np.concatenate([temporal, np.mean(features, axis=0)], axis=0)
+    from . import _lib
+    if features.shape[0] > num_temporal_tokens:
+        raise ValueError(f"{features.shape[0]} frames > {num_temporal_tokens} temporal tokens (callers sample at most {num_temporal_tokens})")
+    if features.dtype not in (torch.float16, torch.bfloat16):
+        features = features.half()
+    return _lib.Context.get(features.device).st_pool(features, num_temporal_tokens, torch.float16).cpu().numpy()
+
+
+def parse_args(argv=None):
+    parser = argparse.ArgumentParser(description="Training")
+    parser.add_argument("--llava", required=True, choices=["1.1", "1.5"], help="LLaVA version")
+    parser.add_argument("--video_dir_path", required=True, help="Path to read the videos from.")
+    parser.add_argument("--clip_feat_path", required=True, help="The output dir to save the features in.")
+    parser.add_argument("--infer_batch", required=False, type=int, default=32, help="Number of frames/images to perform batch inference.")
+    parser.add_argument("--clip_path", default=None, help="local directory of the CLIP checkpoint (default: the hub id of --llava)")
+    return parser.parse_args(argv)
+
+
+def extract_clip_features(video_path, vision_tower, frame_size):
+    """One video -> np.float16 [100 + P, 1024] (the body of the reference's per-video try block, :103-123)."""
+    from . import _lib
+    frames = load_video(video_path, shape=frame_size)
+    dev = vision_tower.device
+    px = _lib.Context.get(dev).preprocess_u8(torch.from_numpy(frames).to(dev), vision_tower.dtype)
+    with torch.no_grad():
+        hidden = vision_tower(px, output_hidden_states=True).hidden_states[-2]
+    return get_spatio_temporal_features(hidden[:, 1:])
+
+
+def run(args, vision_tower=None, save_every=512, log=print):
+    """The reference's main loop (:74-139).  `vision_tower` may be injected (tests, random-init benchmarks)."""
+    os.makedirs(args.clip_feat_path, exist_ok=True)
+    hub_id, frame_size = LLAVA_VERSIONS[args.llava]
+    if vision_tower is None:
+        from .vision_tower import CLIPVisionTower
+        vision_tower = CLIPVisionTower.from_pretrained(args.clip_path or hub_id, torch_dtype=torch.float16, low_cpu_mem_usage=True).cuda().eval()
+    pending = {}
+    counter = 0
+
+    def flush():
+        for key, feats in pending.items():
+            with open(f"{args.clip_feat_path}/{key}.pkl", "wb") as f:
+                pickle.dump(feats, f)
+        pending.clear()
+
+    for video_name in sorted(os.listdir(args.video_dir_path)):
+        video_path = f"{args.video_dir_path}/{video_name}"
+        video_id = video_name.split(".")[0]
+        if os.path.exists(f"{args.clip_feat_path}/{video_id}.pkl"):      # already processed
+            continue
+        try:
+            pending[video_id] = extract_clip_features(video_path, vision_tower, frame_size)
+            counter += 1
+        except Exception as e:                                           # noqa: BLE001 -- the reference prints and continues (:126-127)
+            log(f"Can't process {video_path}: {e}")
+        if counter % save_every == 0:
+            flush()
+    flush()
+    return counter
+
+
+def main(argv=None):
+    run(parse_args(argv))
+
+
+if __name__ == "__main__":
+    main()
