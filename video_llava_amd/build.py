@@ -18,6 +18,9 @@ LIB = os.path.join(HERE, "libpgv.so")
 SOURCES = ["api.hip", "gemm.hip", "elementwise.hip", "vit_attn.hip", "weights.hip", "vit.hip", "llm_kernels.hip", "llm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-ffp-contract=fast"]
+# Attention kernels run VALU softmax on the MFMA results every chunk: keep their accumulators in the VGPR file (hipcc otherwise puts
+# them in AGPRs and moves ~100 registers per chunk back and forth with v_accvgpr_read/write).
+EXTRA_FLAGS = {"vit_attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _hipcc() -> str:
@@ -39,7 +42,7 @@ def _compile(src: str, force: bool, verbose: bool) -> tuple[str, bool]:
     stamp = max(os.path.getmtime(spath), _newest_header())
     if not force and os.path.exists(opath) and os.path.getmtime(opath) >= stamp:
         return opath, False
-    cmd = [_hipcc(), *FLAGS, "-c", spath, "-o", opath]
+    cmd = [_hipcc(), *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", spath, "-o", opath]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
