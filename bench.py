@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--new-tokens", type=int, default=256)
     ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16")
     ap.add_argument("--llm", choices=["7b", "13b"], default="7b")
+    ap.add_argument("--weights", choices=["16bit", "fp8"], default="16bit",
+                    help="fp8 = BASELINE config 5: decoder matrices quantised to e4m3 (per-row power-of-two scales) for the decode weight stream")
     ap.add_argument("--workload", choices=["full", "vision"], default="full",
                     help="full = BASELINE config 3/4 (frames -> answer); vision = config 2 (ViT + pool + projector)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -166,6 +168,8 @@ def main():
                                                        device=dev, dtype=dtype, seed=2))
         vc = model.get_model().vision_config
         vc.vid_patch_token, vc.vid_start_token, vc.vid_end_token, vc.use_vid_start_end = vocab - 3, vocab - 2, vocab - 1, True
+        if args.weights == "fp8":
+            model.quantize_weights_fp8()
     else:
         from video_llava_amd.model.multimodal_projector.builder import HipLinear
         proj = HipLinear(1024, 4096, dtype, dev)
@@ -270,7 +274,7 @@ def main():
                                     f"prefill (~450 tok) -> {NEW} greedy tokens, random-init weights")
                        if args.workload == "full" else
                        f"BASELINE configs[1]: {B} clips/GPU/step x {T} frames -> ViT-L/14 (23 layers) + pool + Linear(1024,4096)",
-                       "clips_per_gpu_per_step": B, "frames_per_clip": T, "new_tokens": NEW, "llm": args.llm if args.workload == "full" else None,
+                       "clips_per_gpu_per_step": B, "frames_per_clip": T, "new_tokens": NEW, "llm": args.llm if args.workload == "full" else None, "llm_weights": args.weights,
                        "parallelism": f"dp{world}"},
             # CLIP-feature stage (preprocess + ViT 23 layers + pool), algorithmic 155.29 GFLOP/frame, per GPU
             "clip_feat_tflops": clip_feat_tflops, "clip_feat_frac_of_mfma_peak": clip_feat_tflops / PEAK_MFMA_TFLOPS,

@@ -139,6 +139,16 @@ int pgv_llm_load_rows(pgv_llm *llm, const char *name, const void *data, int src_
  * rows; growing within them zero-fills the new embed / lm_head rows (the projector checkpoint then overwrites them). */
 int pgv_llm_resize_vocab(pgv_llm *llm, int new_vocab, void *stream);
 int pgv_llm_vocab(const pgv_llm *llm);
+/* fp8 weight path (BASELINE config 5, "13B, fp8 weight path"): after every tensor is loaded, quantise all decoder matrices and
+ * lm_head to OCP e4m3 with one power-of-two scale per output row.  The decode GEMVs then stream the fp8 copies (half the
+ * bytes per token); the 16-bit copies are overwritten with the dequantised values (exactly representable), so prefill, decode
+ * and a CPU oracle fed with pgv_llm_get_weight() all compute with the same weights.  Replaces nothing in the reference (it
+ * has no quantised path); idempotent. */
+int pgv_llm_quantize_fp8(pgv_ctx *ctx, pgv_llm *llm, void *stream);
+int pgv_llm_is_fp8(const pgv_llm *llm);
+/* Read a decoder matrix ("model.layers.N.{self_attn.{q,k,v,o}_proj,mlp.{gate,up,down}_proj}.weight", "lm_head.weight") back as
+ * row-major fp32 [rows, cols] in its HF orientation: the values the path computes with (after quantisation: dequantised). */
+int pgv_llm_get_weight(pgv_ctx *ctx, pgv_llm *llm, const char *name, float *d_out, void *stream);
 
 int pgv_kv_create(pgv_ctx *ctx, pgv_llm *llm, int batch, int max_seq, pgv_kv **out);
 void pgv_kv_destroy(pgv_kv *kv);
@@ -194,6 +204,15 @@ int pgv_gemv(pgv_ctx *ctx, int dtype, int mode, const void *d_W, const void *d_x
  * [rows/16][cols/32][4 k-groups][16 rows][8 elems]: each 1 KiB block is one v_mfma_f32_16x16x32 A fragment in lane order.
  * d_dst must hold ceil(rows/16)*16 * cols elements (zero it first when rows % 16 != 0). */
 int pgv_pack_blocked(pgv_ctx *ctx, int dtype, const void *d_src, int rows, int cols, void *d_dst, void *stream);
+/* Inverse of pgv_pack_blocked: blocked 16-bit [N, K] (N % 16 == 0, K % 32 == 0) -> row-major fp32. */
+int pgv_unpack_blocked(pgv_ctx *ctx, int dtype, const void *d_src_blocked, float *d_dst, int N, int K, void *stream);
+/* Quantise a blocked 16-bit matrix [N, K] (N % 16 == 0, K % 64 == 0) to e4m3 with per-row power-of-two scales: writes the fp8
+ * blocked copy (N*K bytes: block (n/16, k/64) = 1 KiB, lane ((k%32)/8)*16 + n%16, byte ((k/32)%2)*8 + k%8), the scales [N], and
+ * overwrites the 16-bit matrix with the dequantised values. */
+int pgv_quantize_fp8_blocked(pgv_ctx *ctx, int dtype, void *d_w16_blocked, void *d_w8_blocked, float *d_scales, int N, int K, void *stream);
+/* pgv_gemv on the fp8 copy: bit-identical to pgv_gemv on the dequantised 16-bit matrix, half the weight bytes.  modes 0..3. */
+int pgv_gemv_fp8(pgv_ctx *ctx, int dtype, int mode, const void *d_W8, const float *d_scales, const void *d_x, int ldx, void *d_out, int ldo,
+                 int N, int K, int B, void *stream);
 int pgv_layernorm(pgv_ctx *ctx, int dtype, const float *d_x, const float *d_gamma, const float *d_beta, float eps,
                   void *d_y, int rows, int cols, void *stream);
 int pgv_rmsnorm(pgv_ctx *ctx, int dtype, const float *d_x, const float *d_gamma, float eps, void *d_y, int rows, int cols,

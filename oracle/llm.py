@@ -153,3 +153,33 @@ def greedy_generate(w: dict, cfg: LlamaCfg, input_ids, video_feats, vid_start: i
             break
         logits = m.step(tok)
     return (toks, margins) if return_margins else toks
+
+
+def quantize_e4m3_rows(w) -> "torch.Tensor":
+    """CPU twin of csrc/fp8.hip: per-row power-of-two scale s = 2^ceil(log2(amax / 448)), q = e4m3fn(w / s) (round to nearest even),
+    returns the dequantised matrix q * s (fp32).  There is no reference implementation of this step (the reference has no
+    quantised path, BASELINE config 5 is this repo's own extension); the HIP quantiser is tested for bit equality with this twin."""
+    w = torch.as_tensor(w, dtype=torch.float32)
+    amax = w.abs().amax(dim=1, keepdim=True)
+    mant, exp = torch.frexp(amax / 448.0)                       # amax/448 = mant * 2^exp, mant in [0.5, 1)
+    e = torch.where(mant == 0.5, exp - 1, exp)
+    s = torch.where(amax > 0, torch.ldexp(torch.ones_like(amax), e), torch.ones_like(amax))
+    q = (w / s).to(torch.float8_e4m3fn).to(torch.float32)
+    return q * s
+
+
+FP8_KEYS = ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj")
+
+
+def quantize_llama_weights_fp8(w: dict, round16=None) -> dict:
+    """State dict with every decoder matrix and lm_head replaced by its dequantised fp8 version.  `round16`: the model's 16-bit
+    storage dtype (weights are rounded to it BEFORE quantisation, as the library quantises its packed 16-bit copy).
+    q/k/v share one fused matrix in the library but scales are per row, so quantising them separately is identical."""
+    out = dict(w)
+    for k, v in w.items():
+        if k == "lm_head.weight" or (k.endswith(".weight") and any(f".{n}." in k for n in FP8_KEYS)):
+            t = torch.as_tensor(v, dtype=torch.float32)
+            if round16 is not None:
+                t = t.to(round16).to(torch.float32)
+            out[k] = quantize_e4m3_rows(t).numpy()
+    return out

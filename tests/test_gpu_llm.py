@@ -183,3 +183,96 @@ def test_gemv_building_block(ctx, dtype, tol, mode, N, K, B):
     _lib.check(ctx.lib.pgv_gemv(ctx.handle, _lib.dtype_code(dtype), mode, wb.data_ptr(), xd.data_ptr(), K, out.data_ptr(), out.shape[1],
                                 N, K, B, _lib.stream_ptr()))
     assert rel(out, y_ref) < (tol if mode in (0, 2) else 1e-5 + (2e-5 if mode == 3 else 0))
+
+
+# --------------------------------------------------------------------------------------------------
+# fp8 weight path (BASELINE config 5): quantiser == CPU twin bit for bit; fp8 GEMV == 16-bit GEMV on the dequantised matrix bit for
+# bit; a quantised model decodes token-exactly against the oracle run on the dequantised weights.
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("N,K", [(512, 512), (1536, 1024), (48, 11008)])
+def test_fp8_quantizer_matches_cpu_twin(ctx, dtype, N, K):
+    from video_llava_amd import _lib
+    g = torch.Generator().manual_seed(N * 3 + K)
+    w = (torch.randn(N, K, generator=g) * 0.02 * (1 + 10 * torch.rand(N, 1, generator=g))).to(dtype)     # row scales spread over a decade
+    w[3].zero_()                                                                                          # an all-zero row: scale 1
+    wd = w.to(DEV)
+    wb = torch.zeros(N, K, dtype=dtype, device=DEV)
+    _lib.check(ctx.lib.pgv_pack_blocked(ctx.handle, _lib.dtype_code(dtype), wd.data_ptr(), N, K, wb.data_ptr(), _lib.stream_ptr()))
+    w8 = torch.zeros(N * K, dtype=torch.uint8, device=DEV)
+    sc = torch.zeros(N, dtype=torch.float32, device=DEV)
+    _lib.check(ctx.lib.pgv_quantize_fp8_blocked(ctx.handle, _lib.dtype_code(dtype), wb.data_ptr(), w8.data_ptr(), sc.data_ptr(), N, K, _lib.stream_ptr()))
+    back = torch.empty(N, K, dtype=torch.float32, device=DEV)
+    _lib.check(ctx.lib.pgv_unpack_blocked(ctx.handle, _lib.dtype_code(dtype), wb.data_ptr(), back.data_ptr(), N, K, _lib.stream_ptr()))
+    twin = ollm.quantize_e4m3_rows(w.float())
+    assert torch.equal(back.cpu(), twin), float((back.cpu() - twin).abs().max())
+    s = sc.cpu()
+    assert torch.equal(torch.log2(s), torch.log2(s).round()) and float(s[3]) == 1.0                      # powers of two
+    amax = w.float().abs().amax(1)
+    nz = amax > 0
+    assert bool((amax[nz] / s[nz] <= 448).all()) and bool((amax[nz] / s[nz] > 224).all())                # tightest power of two
+    # the fp8 codes reproduce the dequantised matrix: byte (row, col) of the documented layout
+    codes = w8.cpu().view(N // 16, K // 64, 64, 16)
+    r, c = 21 % N, 77 % K
+    byte = codes[r // 16, c // 64, ((c % 32) // 8) * 16 + r % 16, ((c // 32) % 2) * 8 + c % 8]
+    assert float(byte.view(torch.float8_e4m3fn).float() * s[r]) == float(twin[r, c])
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("mode,N,K,B", [(0, 1536, 512, 3), (1, 512, 768, 8), (2, 1536, 512, 16), (3, 512, 1024, 5), (0, 12288, 4096, 8), (2, 22016, 4096, 8)])
+def test_gemv_fp8_bit_equal_to_16bit_on_dequantised(ctx, dtype, mode, N, K, B):
+    from video_llava_amd import _lib
+    g = torch.Generator().manual_seed(N + K + B + 1)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dtype).to(DEV)
+    x = torch.randn(B, K, generator=g).to(dtype).to(DEV)
+    dc = _lib.dtype_code(dtype)
+    wb = torch.zeros(N, K, dtype=dtype, device=DEV)
+    _lib.check(ctx.lib.pgv_pack_blocked(ctx.handle, dc, w.data_ptr(), N, K, wb.data_ptr(), _lib.stream_ptr()))
+    w8 = torch.zeros(N * K, dtype=torch.uint8, device=DEV)
+    sc = torch.zeros(N, dtype=torch.float32, device=DEV)
+    _lib.check(ctx.lib.pgv_quantize_fp8_blocked(ctx.handle, dc, wb.data_ptr(), w8.data_ptr(), sc.data_ptr(), N, K, _lib.stream_ptr()))
+
+    def out_buf():
+        if mode == 0:
+            return torch.empty(B, N, dtype=dtype, device=DEV)
+        if mode == 1:
+            return torch.ones(B, N, dtype=torch.float32, device=DEV)
+        if mode == 2:
+            return torch.empty(B, N // 2, dtype=dtype, device=DEV)
+        return torch.empty(B, N, dtype=torch.float32, device=DEV)
+    o16, o8 = out_buf(), out_buf()
+    _lib.check(ctx.lib.pgv_gemv(ctx.handle, dc, mode, wb.data_ptr(), x.data_ptr(), K, o16.data_ptr(), o16.shape[1], N, K, B, _lib.stream_ptr()))
+    _lib.check(ctx.lib.pgv_gemv_fp8(ctx.handle, dc, mode, w8.data_ptr(), sc.data_ptr(), x.data_ptr(), K, o8.data_ptr(), o8.shape[1], N, K, B,
+                                    _lib.stream_ptr()))
+    assert torch.equal(o16, o8)                                     # same weights, same accumulation order, exact scale
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 1e-3), (torch.bfloat16, 8e-3)])
+def test_llm_fp8_weights_vs_oracle(ctx, golden_dir, dtype, tol):
+    cfg = synth.LlamaCfg(**{**synth.LLAMA_TINY.__dict__, "projector": "linear"})
+    w = synth.make_llama_weights(cfg, seed=77, head_std=0.08)
+    m = _model(cfg, w, dtype).quantize_weights_fp8()
+    assert m.is_fp8
+    wq = ollm.quantize_llama_weights_fp8(w, round16=dtype)
+    for key in ("model.layers.0.self_attn.k_proj.weight", "model.layers.1.mlp.up_proj.weight", "model.layers.1.mlp.down_proj.weight", "lm_head.weight"):
+        assert torch.equal(m.get_weight(key).cpu(), torch.from_numpy(wq[key])), key
+    V = 100 + 4
+    rng = np.random.default_rng(5)
+    feats = torch.from_numpy(rng.standard_normal((V, 1024)).astype(np.float32) * 0.5)
+    ids = [1, 17, 9, cfg.vocab - 2] + [cfg.vocab - 3] * V + [cfg.vocab - 1, 44, 8]
+    NEW = 8
+    ref, margins = ollm.greedy_generate(wq, cfg, ids, feats, cfg.vocab - 2, cfg.vocab - 1, cfg.vocab - 3, NEW, return_margins=True)
+    out = m.generate(torch.tensor([ids]), video_spatio_temporal_features=feats.to(dtype)[None], do_sample=False, max_new_tokens=NEW)
+    got = out[0, len(ids):].tolist()
+    k = next((i for i, mg in enumerate(margins) if mg < 0.02), NEW)
+    assert got[:k] == ref[:k], (got, ref, margins)
+    # a second model loaded with the dequantised weights (no fp8) produces the same logits bit for bit: prefill reads the 16-bit
+    # copy, decode the fp8 copy
+    m2 = _model(cfg, wq, dtype)
+    kv, nxt, lg = m.prefill([ids], feats.to(dtype), 192, want_logits=True)
+    kv2, nxt2, lg2 = m2.prefill([ids], feats.to(dtype), 192, want_logits=True)
+    assert torch.equal(lg, lg2)
+    for _ in range(4):
+        nxt, lg = m.decode_step(kv, nxt, want_logits=True)
+        nxt2, lg2 = m2.decode_step(kv2, nxt2, want_logits=True)
+        assert torch.equal(lg, lg2) and torch.equal(nxt, nxt2)

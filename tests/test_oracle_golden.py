@@ -94,3 +94,20 @@ def test_vit_l14_pooled_fixture(golden_dir):
     g = np.load(path)
     assert g["pooled"].shape == (356, 1024) and g["pooled"].dtype == np.float16
     assert not g["pooled"][8:100].any()
+
+
+def test_fp8_twin_properties():
+    """The CPU twin of the fp8 weight quantiser: per-row power-of-two scales, the tightest ones, dequantised values exactly
+    representable in bf16 and fp16 (so 16-bit prefill weights and fp8 decode weights are the same numbers), error within e4m3's
+    half-ulp, idempotent."""
+    import torch
+    from oracle import llm as ollm
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(64, 256, generator=g) * 0.02 * (1 + 20 * torch.rand(64, 1, generator=g))
+    w[5].zero_()
+    d = ollm.quantize_e4m3_rows(w)
+    assert torch.equal(d.to(torch.bfloat16).float(), d) and torch.equal(d.to(torch.float16).float(), d)
+    assert torch.equal(ollm.quantize_e4m3_rows(d), d)
+    amax = w.abs().amax(1, keepdim=True).clamp_min(1e-30)
+    assert float(((d - w).abs() / amax).max()) <= 2.0 ** -4 + 1e-6          # 3 mantissa bits: half-ulp at the top binade = 16/448 < 2^-4
+    assert not d[5].any()

@@ -68,6 +68,12 @@ PROTOTYPES = {
     "pgv_vit_attention": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pgv_gemv": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "pgv_pack_blocked": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp]),
+    "pgv_unpack_blocked": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp]),
+    "pgv_quantize_fp8_blocked": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _vp]),
+    "pgv_gemv_fp8": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    "pgv_llm_quantize_fp8": (_i, [_vp, _vp, _vp]),
+    "pgv_llm_is_fp8": (_i, [_vp]),
+    "pgv_llm_get_weight": (_i, [_vp, _vp, C.c_char_p, _vp, _vp]),
     "pgv_layernorm": (_i, [_vp, _i, _vp, _vp, _vp, _f, _vp, _i, _i, _vp]),
     "pgv_rmsnorm": (_i, [_vp, _i, _vp, _vp, _f, _vp, _i, _i, _vp]),
 }

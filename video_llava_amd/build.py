@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libpgv.so")
-SOURCES = ["api.hip", "gemm.hip", "elementwise.hip", "vit_attn.hip", "weights.hip", "vit.hip", "llm_kernels.hip", "llm.hip"]
+SOURCES = ["api.hip", "gemm.hip", "elementwise.hip", "vit_attn.hip", "weights.hip", "fp8.hip", "vit.hip", "llm_kernels.hip", "llm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-ffp-contract=fast"]
 # Attention kernels run VALU softmax on the MFMA results every chunk: keep their accumulators in the VGPR file (hipcc otherwise puts

@@ -17,7 +17,10 @@ int pgv_launch_rope_kv_write(int dtype, void* qkv, const int* row_b, const int* 
 int pgv_launch_prefill_attn(pgv_ctx* ctx, int dtype, const void* qkv, void* out, const void* Kc, const void* Vc, const int* cu, int B, int max_len,
                             int H, int heads, int max_seq, double flops, hipStream_t s);
 int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void* x, int ldx, void* out, int ldo, int N, int K, int B, hipStream_t s,
-                    int splits = 1);
+                    int splits = 1, const float* wscale = nullptr);
+int pgv_launch_quantize_fp8(int dtype, void* w16_blocked, void* w8_blocked, float* scales, long long N, long long K, hipStream_t s);
+int pgv_launch_unpack_blocked(int dtype, const void* src, float* dst, long long N, long long K, long long row_blk, long long blk_stride, long long row_off,
+                              long long rows, hipStream_t s);
 int pgv_launch_rms_resid(int dtype, float* resid, const float* part, int nparts, int B, const float* gamma, float eps, void* xn, int H, hipStream_t s);
 int pgv_launch_decode_attn(pgv_ctx* ctx, int dtype, const void* qkv, const int* pos, const void* rope, void* Kc, void* Vc, void* out, int B, int H,
                            int heads, int max_seq, double bytes, hipStream_t s);
@@ -33,6 +36,9 @@ constexpr int kHD = 128;
 struct LlmLayer {
     float *in_g, *post_g;
     void *wqkv, *wo, *wgu, *wdown;
+    // fp8 decode copies (pgv_llm_quantize_fp8): e4m3 blocked matrices + per-row power-of-two scales; null until quantised
+    void *q_wqkv = nullptr, *q_wo = nullptr, *q_wgu = nullptr, *q_wdown = nullptr;
+    float *s_wqkv = nullptr, *s_wo = nullptr, *s_wgu = nullptr, *s_wdown = nullptr;
 };
 
 struct pgv_llm {
@@ -48,6 +54,9 @@ struct pgv_llm {
     std::set<std::string> loaded;
     int expected = 0;
     int vocab_cap = 0;   // allocated rows of embed / lm_head (cfg.vocab at creation + 64 spare)
+    char* blob8 = nullptr;   // fp8 copies + scales (decode weight stream halves; the 16-bit copies hold the dequantised values)
+    void* q_head = nullptr; float* s_head = nullptr;
+    bool fp8 = false;
 };
 
 struct pgv_kv {
@@ -120,6 +129,7 @@ extern "C" int pgv_llm_create(pgv_ctx* ctx, const pgv_llm_config* cfg, int dtype
 extern "C" void pgv_llm_destroy(pgv_llm* llm) {
     if (!llm) return;
     if (llm->blob) (void)hipFree(llm->blob);
+    if (llm->blob8) (void)hipFree(llm->blob8);
     delete llm;
 }
 
@@ -188,6 +198,72 @@ extern "C" int pgv_llm_load_tensor(pgv_llm* m, const char* name_in, const void* 
 }
 
 // ---------------------------------------------------------------------------------------------
+// fp8 weight path (BASELINE config 5): quantise every decoder matrix + lm_head once, after loading
+// ---------------------------------------------------------------------------------------------
+extern "C" int pgv_llm_quantize_fp8(pgv_ctx* ctx, pgv_llm* m, void* stream) {
+    PGV_CHECK(ctx && m, "pgv_llm_quantize_fp8: null argument");
+    if (pgv_llm_missing(m) != 0) { pgv_set_error("pgv_llm_quantize_fp8: %d weight tensors not loaded", pgv_llm_missing(m)); return PGV_ESTATE; }
+    if (m->fp8) return PGV_OK;
+    PGV_CHECK(m->cfg.hidden % 64 == 0 && m->cfg.inter % 64 == 0, "pgv_llm_quantize_fp8: hidden and intermediate sizes must be multiples of 64");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t H = m->cfg.hidden, I = m->cfg.inter, V = m->vocab_cap, L = m->cfg.layers;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += pgv_align(bytes); return o; };
+    struct LO { size_t qkv, o, gu, down, sqkv, so, sgu, sdown; };
+    std::vector<LO> lo(L);
+    const size_t o_head = take(V * H), o_shead = take(V * 4);
+    for (size_t i = 0; i < L; ++i) {
+        lo[i].qkv = take(3 * H * H); lo[i].o = take(H * H); lo[i].gu = take(2 * I * H); lo[i].down = take(H * I);
+        lo[i].sqkv = take(3 * H * 4); lo[i].so = take(H * 4); lo[i].sgu = take(2 * I * 4); lo[i].sdown = take(H * 4);
+    }
+    hipError_t e = hipMalloc((void**)&m->blob8, off);
+    if (e != hipSuccess) { pgv_set_error("pgv_llm_quantize_fp8: hipMalloc(%zu MiB): %s", off >> 20, hipGetErrorString(e)); return PGV_ENOMEM; }
+    char* b = m->blob8;
+    m->q_head = b + o_head; m->s_head = (float*)(b + o_shead);
+    PGV_TRY(pgv_launch_quantize_fp8(m->dtype, m->lm_head, m->q_head, m->s_head, (long long)V, (long long)H, s));
+    for (size_t i = 0; i < L; ++i) {
+        LlmLayer& l = m->layers[i];
+        l.q_wqkv = b + lo[i].qkv; l.q_wo = b + lo[i].o; l.q_wgu = b + lo[i].gu; l.q_wdown = b + lo[i].down;
+        l.s_wqkv = (float*)(b + lo[i].sqkv); l.s_wo = (float*)(b + lo[i].so); l.s_wgu = (float*)(b + lo[i].sgu); l.s_wdown = (float*)(b + lo[i].sdown);
+        PGV_TRY(pgv_launch_quantize_fp8(m->dtype, l.wqkv, l.q_wqkv, l.s_wqkv, 3 * (long long)H, (long long)H, s));
+        PGV_TRY(pgv_launch_quantize_fp8(m->dtype, l.wo, l.q_wo, l.s_wo, (long long)H, (long long)H, s));
+        PGV_TRY(pgv_launch_quantize_fp8(m->dtype, l.wgu, l.q_wgu, l.s_wgu, 2 * (long long)I, (long long)H, s));
+        PGV_TRY(pgv_launch_quantize_fp8(m->dtype, l.wdown, l.q_wdown, l.s_wdown, (long long)H, (long long)I, s));
+    }
+    PGV_HIP(hipStreamSynchronize(s));
+    m->fp8 = true;
+    return PGV_OK;
+}
+
+extern "C" int pgv_llm_is_fp8(const pgv_llm* m) { return (m && m->fp8) ? 1 : 0; }
+
+// Read one decoder matrix back as row-major fp32 [rows, cols] under its HF key (after quantisation: the dequantised values the
+// whole path computes with) -- what a parity test or a checkpoint writer needs.
+extern "C" int pgv_llm_get_weight(pgv_ctx* ctx, pgv_llm* m, const char* name_in, float* d_out, void* stream) {
+    PGV_CHECK(ctx && m && name_in && d_out, "pgv_llm_get_weight: null argument");
+    std::string name(name_in);
+    const long long H = m->cfg.hidden, I = m->cfg.inter, V = m->cfg.vocab;
+    hipStream_t s = (hipStream_t)stream;
+    if (name == "lm_head.weight") return pgv_launch_unpack_blocked(m->dtype, m->lm_head, d_out, m->vocab_cap, H, 0, 0, 0, V, s);
+    if (name.rfind("model.layers.", 0) != 0) { pgv_set_error("pgv_llm_get_weight: unsupported key '%s'", name_in); return PGV_ENAME; }
+    const char* p = name.c_str() + 13;
+    char* end = nullptr;
+    long li = strtol(p, &end, 10);
+    if (end == p || *end != '.' || li < 0 || li >= m->cfg.layers) { pgv_set_error("pgv_llm_get_weight: bad layer index in '%s'", name_in); return PGV_ENAME; }
+    std::string rest(end + 1);
+    const LlmLayer& l = m->layers[li];
+    if (rest == "self_attn.q_proj.weight") return pgv_launch_unpack_blocked(m->dtype, l.wqkv, d_out, 3 * H, H, 0, 0, 0, H, s);
+    if (rest == "self_attn.k_proj.weight") return pgv_launch_unpack_blocked(m->dtype, l.wqkv, d_out, 3 * H, H, 0, 0, H, H, s);
+    if (rest == "self_attn.v_proj.weight") return pgv_launch_unpack_blocked(m->dtype, l.wqkv, d_out, 3 * H, H, 0, 0, 2 * H, H, s);
+    if (rest == "self_attn.o_proj.weight") return pgv_launch_unpack_blocked(m->dtype, l.wo, d_out, H, H, 0, 0, 0, H, s);
+    if (rest == "mlp.gate_proj.weight") return pgv_launch_unpack_blocked(m->dtype, l.wgu, d_out, 2 * I, H, 32, 64, 0, I, s);
+    if (rest == "mlp.up_proj.weight") return pgv_launch_unpack_blocked(m->dtype, l.wgu, d_out, 2 * I, H, 32, 64, 32, I, s);
+    if (rest == "mlp.down_proj.weight") return pgv_launch_unpack_blocked(m->dtype, l.wdown, d_out, H, I, 0, 0, 0, H, s);
+    pgv_set_error("pgv_llm_get_weight: unsupported key '%s'", name_in);
+    return PGV_ENAME;
+}
+
+// ---------------------------------------------------------------------------------------------
 // KV cache
 // ---------------------------------------------------------------------------------------------
 extern "C" int pgv_kv_create(pgv_ctx* ctx, pgv_llm* llm, int batch, int max_seq, pgv_kv** out) {
@@ -232,7 +308,7 @@ extern "C" int pgv_kv_len(const pgv_kv* kv, int b) { return (kv && b >= 0 && b <
 static int lm_head_and_pick(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int B, int eos, int flags, hipStream_t s, int nparts = 0) {
     const int H = m->cfg.hidden, V = m->cfg.vocab;
     PGV_TRY(pgv_launch_rms_resid(m->dtype, kv->resid, kv->part, nparts, B, m->norm_g, m->cfg.eps, kv->xn, H, s));
-    PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_F32, m->lm_head, kv->xn, H, kv->logits, V, V, H, B, s));
+    PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_F32, m->fp8 ? m->q_head : m->lm_head, kv->xn, H, kv->logits, V, V, H, B, s, 1, m->fp8 ? m->s_head : nullptr));
     PGV_TRY(pgv_launch_argmax(kv->logits, V, B, kv->d_cur, kv->d_pos, kv->d_step, kv->d_hist, kv->max_seq, kv->d_done, eos, flags, s));
     return PGV_OK;
 }
@@ -332,12 +408,13 @@ static int decode_enqueue(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int eos, int fla
         const LlmLayer& l = m->layers[li];
         // input norm; for li > 0 it also folds the previous layer's down_proj split-K partials into the residual
         PGV_TRY(pgv_launch_rms_resid(m->dtype, kv->resid, kv->part, li == 0 ? 0 : kSplits, B, l.in_g, m->cfg.eps, kv->xn, H, s));
-        PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_STORE16, l.wqkv, kv->xn, H, kv->qkv, 3 * H, 3 * H, H, B, s));
+        const bool q8 = m->fp8;
+        PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_STORE16, q8 ? l.q_wqkv : l.wqkv, kv->xn, H, kv->qkv, 3 * H, 3 * H, H, B, s, 1, q8 ? l.s_wqkv : nullptr));
         PGV_TRY(pgv_launch_decode_attn(ctx, m->dtype, kv->qkv, kv->d_pos, m->rope, kv->Kc[li], kv->Vc[li], kv->ao, B, H, heads, kv->max_seq, kv_bytes, s));
-        PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_PART, l.wo, kv->ao, H, kv->part, H, H, H, B, s, kSplits));
+        PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_PART, q8 ? l.q_wo : l.wo, kv->ao, H, kv->part, H, H, H, B, s, kSplits, q8 ? l.s_wo : nullptr));
         PGV_TRY(pgv_launch_rms_resid(m->dtype, kv->resid, kv->part, kSplits, B, l.post_g, m->cfg.eps, kv->xn, H, s));
-        PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_SWIGLU, l.wgu, kv->xn, H, kv->act, I, 2 * I, H, B, s));
-        PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_PART, l.wdown, kv->act, I, kv->part, H, H, I, B, s, kSplits));
+        PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_SWIGLU, q8 ? l.q_wgu : l.wgu, kv->xn, H, kv->act, I, 2 * I, H, B, s, 1, q8 ? l.s_wgu : nullptr));
+        PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_PART, q8 ? l.q_wdown : l.wdown, kv->act, I, kv->part, H, H, I, B, s, kSplits, q8 ? l.s_wdown : nullptr));
     }
     PGV_TRY(lm_head_and_pick(ctx, m, kv, B, eos, flags, s, m->cfg.layers > 0 ? kSplits : 0));
     return PGV_OK;

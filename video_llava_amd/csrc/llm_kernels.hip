@@ -260,9 +260,23 @@ struct GemvArgs {
     const char* W; const char* x; char* out;
     int N, K, B, ldx, ldo;
     int kb_per;     // k-blocks (of 32) per split; gridDim.y splits write fp32 partials [split][B][ldo] in GV_PART mode
+    const float* wscale;   // W8 = true: per-row power-of-two scales of the fp8 matrix (fp8.hip)
 };
 
-template <typename T, int MODE>
+// W8 = true streams the fp8 (e4m3) blocked copy of the matrix: one 16-byte load per lane carries the A fragments of TWO consecutive
+// k-blocks, the codes are widened to the activation dtype in registers (exact) and the per-row scale multiplies the fp32 result, so the
+// output is bit-identical to the 16-bit kernel on the dequantised matrix while the weight stream is half as long.
+template <typename T>
+__device__ __forceinline__ typename T::v8 fp8x8_to_v8(unsigned lo, unsigned hi) {
+    const f32x2_t a = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, true);
+    const f32x2_t c = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, false), d = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, true);
+    typename T::v8 r;
+    r[0] = T::from_f32(a[0]); r[1] = T::from_f32(a[1]); r[2] = T::from_f32(b[0]); r[3] = T::from_f32(b[1]);
+    r[4] = T::from_f32(c[0]); r[5] = T::from_f32(c[1]); r[6] = T::from_f32(d[0]); r[7] = T::from_f32(d[1]);
+    return r;
+}
+
+template <typename T, int MODE, bool W8>
 __global__ __launch_bounds__(512) void gemv_mfma_kernel(GemvArgs p) {
     constexpr int TILES = (MODE == GV_SWIGLU) ? 2 : 1;
     __shared__ f32x4_t red[8][TILES][64];
@@ -279,35 +293,91 @@ __global__ __launch_bounds__(512) void gemv_mfma_kernel(GemvArgs p) {
     } else {
         rb[0] = blockIdx.x;
     }
-    const char* wp[TILES];
-#pragma unroll
-    for (int t = 0; t < TILES; ++t) wp[t] = p.W + ((size_t)rb[t] * kblocks) * 1024 + lane * 16;
     const char* xp = p.x + ((size_t)min(l15, p.B - 1) * p.ldx + kg * 8) * 2;
     f32x4_t acc[TILES];
 #pragma unroll
     for (int t = 0; t < TILES; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    constexpr int U = (TILES == 2) ? 4 : 8;
-    const int kb_end = min(kblocks, (int)(blockIdx.y + 1) * p.kb_per);
-    int kk = blockIdx.y * p.kb_per + w;
-    for (; kk + 8 * (U - 1) < kb_end; kk += 8 * U) {
-        typename T::v8 wf[U][TILES], xf[U];
+    if constexpr (W8) {
+        // k is walked in blocks of 64 (one 16-byte load = two MFMA k-blocks); kb_per counts 32-blocks and is even here
+        const int k64 = p.K >> 6;
+        const char* wp[TILES];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int t = 0; t < TILES; ++t) wp[t] = p.W + ((size_t)rb[t] * k64) * 1024 + lane * 16;
+        constexpr int U = (TILES == 2) ? 4 : 8;
+        const int j_end = min(k64, (int)(blockIdx.y + 1) * (p.kb_per >> 1));
+        int j = blockIdx.y * (p.kb_per >> 1) + w;
+        for (; j + 8 * (U - 1) < j_end; j += 8 * U) {
+            u32x4_t wr[U][TILES];
+            typename T::v8 xf[U][2];
 #pragma unroll
-            for (int t = 0; t < TILES; ++t) wf[u][t] = __builtin_nontemporal_load((const typename T::v8*)(wp[t] + (size_t)(kk + 8 * u) * 1024));
-            xf[u] = *(const typename T::v8*)(xp + (size_t)(kk + 8 * u) * 64);
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int t = 0; t < TILES; ++t) wr[u][t] = __builtin_nontemporal_load((const u32x4_t*)(wp[t] + (size_t)(j + 8 * u) * 1024));
+                xf[u][0] = *(const typename T::v8*)(xp + (size_t)(2 * (j + 8 * u)) * 64);
+                xf[u][1] = *(const typename T::v8*)(xp + (size_t)(2 * (j + 8 * u) + 1) * 64);
+            }
+            __builtin_amdgcn_sched_barrier(0);      // every load of the batch is in flight before the first use (hipcc otherwise sinks
+                                                    // each load to its MFMA to save registers and waits vmcnt(0) per k-block)
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int t = 0; t < TILES; ++t) {
+                    acc[t] = T::mfma16(fp8x8_to_v8<T>(wr[u][t][0], wr[u][t][1]), xf[u][0], acc[t]);
+                    acc[t] = T::mfma16(fp8x8_to_v8<T>(wr[u][t][2], wr[u][t][3]), xf[u][1], acc[t]);
+                }
         }
+        for (; j < j_end; j += 8) {
+            const typename T::v8 x0 = *(const typename T::v8*)(xp + (size_t)(2 * j) * 64), x1 = *(const typename T::v8*)(xp + (size_t)(2 * j + 1) * 64);
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+            for (int t = 0; t < TILES; ++t) {
+                const u32x4_t wr = __builtin_nontemporal_load((const u32x4_t*)(wp[t] + (size_t)j * 1024));
+                acc[t] = T::mfma16(fp8x8_to_v8<T>(wr[0], wr[1]), x0, acc[t]);
+                acc[t] = T::mfma16(fp8x8_to_v8<T>(wr[2], wr[3]), x1, acc[t]);
+            }
+        }
+    } else {
+        // Same k order as the fp8 branch (wave w takes the 64-column groups w, w+8, ...; inside a group the two 32-blocks in order), so
+        // the two kernels accumulate identically and the fp8 path is bit-equal to the 16-bit path on the dequantised matrix.
+        const char* wp[TILES];
 #pragma unroll
-            for (int t = 0; t < TILES; ++t) acc[t] = T::mfma16(wf[u][t], xf[u], acc[t]);
-    }
-    for (; kk < kb_end; kk += 8) {
-        const typename T::v8 xf = *(const typename T::v8*)(xp + (size_t)kk * 64);
+        for (int t = 0; t < TILES; ++t) wp[t] = p.W + ((size_t)rb[t] * kblocks) * 1024 + lane * 16;
+        constexpr int U = (TILES == 2) ? 2 : 4;
+        const int kb_end = min(kblocks, (int)(blockIdx.y + 1) * p.kb_per);       // 32-blocks; kb_per is even
+        const int j_end = (kb_end + 1) >> 1;                                     // 64-groups (the last may hold one 32-block)
+        int j = ((blockIdx.y * p.kb_per) >> 1) + w;
+        for (; j + 8 * (U - 1) < j_end && 2 * (j + 8 * (U - 1)) + 1 < kb_end; j += 8 * U) {
+            typename T::v8 wf[U][2][TILES], xf[U][2];
 #pragma unroll
-        for (int t = 0; t < TILES; ++t) {
-            const typename T::v8 wf = __builtin_nontemporal_load((const typename T::v8*)(wp[t] + (size_t)kk * 1024));
-            acc[t] = T::mfma16(wf, xf, acc[t]);
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const size_t kb = (size_t)(2 * (j + 8 * u) + h);
+#pragma unroll
+                    for (int t = 0; t < TILES; ++t) wf[u][h][t] = __builtin_nontemporal_load((const typename T::v8*)(wp[t] + kb * 1024));
+                    xf[u][h] = *(const typename T::v8*)(xp + kb * 64);
+                }
+            __builtin_amdgcn_sched_barrier(0);      // as above: the whole batch in flight before the first MFMA
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int t = 0; t < TILES; ++t) {
+                    acc[t] = T::mfma16(wf[u][0][t], xf[u][0], acc[t]);
+                    acc[t] = T::mfma16(wf[u][1][t], xf[u][1], acc[t]);
+                }
+        }
+        for (; j < j_end; j += 8) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int kb = 2 * j + h;
+                if (kb < kb_end) {
+                    const typename T::v8 xf = *(const typename T::v8*)(xp + (size_t)kb * 64);
+#pragma unroll
+                    for (int t = 0; t < TILES; ++t) {
+                        const typename T::v8 wf = __builtin_nontemporal_load((const typename T::v8*)(wp[t] + (size_t)kb * 1024));
+                        acc[t] = T::mfma16(wf, xf, acc[t]);
+                    }
+                }
+            }
         }
     }
 #pragma unroll
@@ -320,6 +390,10 @@ __global__ __launch_bounds__(512) void gemv_mfma_kernel(GemvArgs p) {
         tot[t] = red[0][t][lane];
 #pragma unroll
         for (int ww = 1; ww < 8; ++ww) tot[t] += red[ww][t][lane];
+    }
+    if constexpr (W8) {                                           // per-row power-of-two scale: exact in fp32
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) tot[t] *= *(const f32x4_t*)(p.wscale + rb[t] * 16 + kg * 4);
     }
     // lane holds D[n = kg*4 + r][b = l15]
     const int b = l15;
@@ -592,29 +666,33 @@ int pgv_launch_rms_resid(int dtype, float* resid, const float* part, int nparts,
 }
 
 int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void* x, int ldx, void* out, int ldo, int N, int K, int B, hipStream_t s,
-                    int splits) {
+                    int splits, const float* wscale) {
     PGV_CHECK(B >= 1 && B <= 16, "gemv: batch %d outside [1,16]", B);
     PGV_CHECK(K % 32 == 0, "gemv: K=%d must be a multiple of 32", K);
+    const bool w8 = wscale != nullptr;                  // W is the fp8 blocked copy (fp8.hip) with per-row scales
     GemvArgs a;
-    a.W = (const char*)W; a.x = (const char*)x; a.out = (char*)out; a.N = N; a.K = K; a.B = B; a.ldx = ldx; a.ldo = ldo;
+    a.W = (const char*)W; a.x = (const char*)x; a.out = (char*)out; a.N = N; a.K = K; a.B = B; a.ldx = ldx; a.ldo = ldo; a.wscale = wscale;
     PGV_CHECK(splits >= 1 && (splits == 1 || mode == GV_PART), "gemv: split-K needs the partial-output mode");
-    a.kb_per = ((K / 32) + splits - 1) / splits;
+    a.kb_per = ((((K / 32) + splits - 1) / splits) + 1) & ~1;      // 32-blocks per split, even: splits fall on 64-column boundaries
+    if (w8) PGV_CHECK(K % 64 == 0, "gemv fp8: K=%d must be a multiple of 64", K);
     int grid;
     // W must be in the fragment-blocked layout with its row count padded to a multiple of 16 (zero rows)
     if (mode == GV_SWIGLU) { PGV_CHECK(N % 64 == 0, "gemv swiglu: N=%d must be a multiple of 64", N); grid = N / 32; }
     else { if (mode != GV_F32) PGV_CHECK(N % 16 == 0, "gemv: N=%d must be a multiple of 16", N); grid = (N + 15) / 16; }
     pgv_prof_begin(ctx, 3, s);
-#define PGV_GEMV(MODE_) PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gemv_mfma_kernel<T, MODE_>), dim3(grid, splits), dim3(512), 0, s, a))
+#define PGV_GEMV(MODE_, W8_) PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gemv_mfma_kernel<T, MODE_, W8_>), dim3(grid, splits), dim3(512), 0, s, a))
+#define PGV_GEMV2(MODE_) do { if (w8) PGV_GEMV(MODE_, true); else PGV_GEMV(MODE_, false); } while (0)
     switch (mode) {
-        case GV_STORE16: PGV_GEMV(GV_STORE16); break;
-        case GV_RESID: PGV_GEMV(GV_RESID); break;
-        case GV_SWIGLU: PGV_GEMV(GV_SWIGLU); break;
-        case GV_F32: PGV_GEMV(GV_F32); break;
-        case GV_PART: PGV_GEMV(GV_PART); break;
+        case GV_STORE16: PGV_GEMV2(GV_STORE16); break;
+        case GV_RESID: PGV_GEMV2(GV_RESID); break;
+        case GV_SWIGLU: PGV_GEMV2(GV_SWIGLU); break;
+        case GV_F32: PGV_GEMV2(GV_F32); break;
+        case GV_PART: PGV_GEMV2(GV_PART); break;
         default: pgv_set_error("gemv: bad mode %d", mode); return PGV_EINVAL;
     }
+#undef PGV_GEMV2
 #undef PGV_GEMV
-    pgv_prof_end(ctx, 3, s, 2.0 * B * (double)N * K, 2.0 * (double)N * K);
+    pgv_prof_end(ctx, 3, s, 2.0 * B * (double)N * K, (w8 ? 1.0 : 2.0) * (double)N * K);
     return PGV_OK;
 }
 
@@ -639,7 +717,7 @@ extern "C" int pgv_gemv(pgv_ctx* ctx, int dtype, int mode, const void* d_W, cons
                         void* stream) {
     PGV_CHECK(ctx && d_W && d_x && d_out, "pgv_gemv: null argument");
     PGV_CHECK(mode >= 0 && mode <= 3, "pgv_gemv: mode %d outside [0,3]", mode);
-    return pgv_launch_gemv(ctx, dtype, mode, d_W, d_x, ldx, d_out, ldo, N, K, B, (hipStream_t)stream, 1);
+    return pgv_launch_gemv(ctx, dtype, mode, d_W, d_x, ldx, d_out, ldo, N, K, B, (hipStream_t)stream, 1, nullptr);
 }
 
 #include "weights.h"
@@ -648,4 +726,11 @@ extern "C" int pgv_pack_blocked(pgv_ctx* ctx, int dtype, const void* d_src, int 
     PackDst d;
     d.ptr = d_dst; d.dst_dtype = dtype; d.rows = rows; d.cols = cols; d.dst_stride = cols; d.blocked = true;
     return pgv_pack_tensor(d, d_src, dtype, 1, (hipStream_t)stream);
+}
+
+extern "C" int pgv_gemv_fp8(pgv_ctx* ctx, int dtype, int mode, const void* d_W8, const float* d_scales, const void* d_x, int ldx, void* d_out, int ldo, int N,
+                            int K, int B, void* stream) {
+    PGV_CHECK(ctx && d_W8 && d_scales && d_x && d_out, "pgv_gemv_fp8: null argument");
+    PGV_CHECK(mode >= GV_STORE16 && mode <= GV_F32, "pgv_gemv_fp8: mode %d outside [0,3]", mode);
+    return pgv_launch_gemv(ctx, dtype, mode, d_W8, d_x, ldx, d_out, ldo, N, K, B, (hipStream_t)stream, 1, d_scales);
 }

@@ -132,6 +132,35 @@ class VideoChatGPTLlamaForCausalLM(nn.Module):
     def vocab_size(self) -> int:
         return self.ctx.lib.pgv_llm_vocab(self.handle)
 
+    # ---- fp8 weight path (BASELINE config 5) ------------------------------------------------------------
+    def quantize_weights_fp8(self):
+        """Quantise every decoder matrix and lm_head to e4m3 with per-row power-of-two scales (pgv_llm_quantize_fp8): decode then
+        streams half the weight bytes per token; prefill and decode both compute with the dequantised values, which
+        `get_weight(key)` returns for a checkpoint writer or a parity oracle.  Call after load_state_dict."""
+        _lib.check(self.ctx.lib.pgv_llm_quantize_fp8(self.ctx.handle, self.handle, _lib.stream_ptr(self.device_)), "pgv_llm_quantize_fp8")
+        return self
+
+    @property
+    def is_fp8(self) -> bool:
+        return bool(self.ctx.lib.pgv_llm_is_fp8(self.handle))
+
+    def get_weight(self, key: str) -> torch.Tensor:
+        """fp32 [out, in] copy of a decoder matrix / lm_head under its HF key, as the kernels see it (dequantised after fp8)."""
+        c = self.config
+        H, I = c.hidden_size, c.intermediate_size
+        if key == "lm_head.weight":
+            shape = (self.vocab_size, H)
+        elif key.endswith(("gate_proj.weight", "up_proj.weight")):
+            shape = (I, H)
+        elif key.endswith("down_proj.weight"):
+            shape = (H, I)
+        else:
+            shape = (H, H)
+        out = torch.empty(shape, dtype=torch.float32, device=self.device_)
+        _lib.check(self.ctx.lib.pgv_llm_get_weight(self.ctx.handle, self.handle, key.encode(), out.data_ptr(), _lib.stream_ptr(self.device_)),
+                   "pgv_llm_get_weight")
+        return out
+
     def resize_token_embeddings(self, new_num_tokens: int):
         """eval/model_utils.py:119: grow embed_tokens / lm_head for the three video tokens."""
         _lib.check(self.ctx.lib.pgv_llm_resize_vocab(self.handle, int(new_num_tokens), _lib.stream_ptr(self.device_)),
