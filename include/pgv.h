@@ -55,6 +55,8 @@ int pgv_prof_enable(pgv_ctx *ctx, int on);
 int pgv_prof_reset(pgv_ctx *ctx);
 /* synchronises the recorded events; fills launches / total ms / algorithmic flops / algorithmic bytes */
 int pgv_prof_get(pgv_ctx *ctx, int family, int64_t *launches, double *ms, double *flops, double *bytes);
+/* mean elapsed ms of an EMPTY event pair on `stream`: the fixed per-launch cost included in pgv_prof_get's totals */
+int pgv_prof_calibrate(pgv_ctx *ctx, void *stream, int n, double *ms_per_pair);
 
 /* ---- CLIP vision tower ------------------------------------------------------------------------
  * Replaces `vision_tower(image_tensor, output_hidden_states=True)` -- video_chatgpt/inference.py:93,

@@ -43,6 +43,7 @@ PROTOTYPES = {
     "pgv_prof_enable": (_i, [_vp, _i]),
     "pgv_prof_reset": (_i, [_vp]),
     "pgv_prof_get": (_i, [_vp, _i, C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "pgv_prof_calibrate": (_i, [_vp, _vp, _i, C.POINTER(C.c_double)]),
     "pgv_vit_create": (_i, [_vp, C.POINTER(VitConfig), _i, C.POINTER(_vp)]),
     "pgv_vit_destroy": (None, [_vp]),
     "pgv_vit_load_tensor": (_i, [_vp, C.c_char_p, _vp, _i, _i, _vp]),
@@ -169,6 +170,12 @@ class Context:
             check(self.lib.pgv_prof_get(self.handle, i, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)))
             out[name] = {"launches": n.value, "ms": ms.value, "flops": fl.value, "bytes": by.value}
         return out
+
+    def prof_calibrate(self, n: int = 512) -> float:
+        """Mean elapsed ms of an empty event pair on the current stream (the fixed cost inside every per-launch measurement)."""
+        ms = C.c_double()
+        check(self.lib.pgv_prof_calibrate(self.handle, stream_ptr(), n, C.byref(ms)), "pgv_prof_calibrate")
+        return ms.value
 
     # ---- thin op wrappers used by tests and by the Python mirrors ------------------------------
     def gemm(self, a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor | None = None, epi: int = EPI_NONE,

@@ -131,3 +131,19 @@ extern "C" int pgv_prof_get(pgv_ctx* ctx, int family, int64_t* launches, double*
     if (bytes) *bytes = f.bytes;
     return PGV_OK;
 }
+
+// Mean elapsed time of an EMPTY hipEvent pair on `stream` (nothing enqueued between the two records): the fixed cost every
+// per-launch measurement of pgv_prof_get carries.  bench.py subtracts it from the per-launch averages of short kernels.
+extern "C" int pgv_prof_calibrate(pgv_ctx* ctx, void* stream, int n, double* ms_per_pair) {
+    PGV_CHECK(ctx != nullptr && ms_per_pair != nullptr && n >= 1 && n <= 4096, "pgv_prof_calibrate: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    std::vector<hipEvent_t> ev(2 * (size_t)n);
+    for (auto& e : ev) PGV_HIP(hipEventCreate(&e));
+    for (int i = 0; i < n; ++i) { PGV_HIP(hipEventRecord(ev[2 * i], s)); PGV_HIP(hipEventRecord(ev[2 * i + 1], s)); }
+    PGV_HIP(hipEventSynchronize(ev.back()));
+    double tot = 0;
+    for (int i = 0; i < n; ++i) { float t = 0; PGV_HIP(hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1])); tot += t; }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    *ms_per_pair = tot / n;
+    return PGV_OK;
+}
