@@ -168,3 +168,39 @@ def bench_gemm_data(ctx, dtype=torch.bfloat16):
 
 if "data" in sys.argv[1:]:
     bench_gemm_data(_lib.Context.get(0))
+
+
+def bench_prefetch(ctx, dtype=torch.bfloat16):
+    """Does a weight matrix that was just touched (L2 / Infinity Cache resident) stream faster through the decode GEMV than a cold one?
+    Rotates over enough copies to be HBM-cold; 'touch' = a torch reduction over the first `mb` MB right before the GEMV."""
+    import ctypes as C
+    lib = ctx.lib
+    print("== gemv after prefetch (qkv shape N=12288 K=4096 B=8) ==")
+    N, K, B = 12288, 4096, 8
+    ncopy = 8
+    ws = []
+    for _ in range(ncopy):
+        src = (torch.randn(N, K, device=DEV) * 0.02).to(dtype)
+        dst = torch.zeros(N, K, device=DEV, dtype=dtype)
+        _lib.check(lib.pgv_pack_blocked(ctx.handle, _lib.dtype_code(dtype), src.data_ptr(), N, K, dst.data_ptr(), _lib.stream_ptr()))
+        ws.append(dst)
+    x = torch.randn(B, K, device=DEV).to(dtype)
+    out = torch.empty(B, N, device=DEV, dtype=dtype)
+    for mb in (0, 8, 32, 100):
+        ts = []
+        for it in range(24):
+            w = ws[it % ncopy]
+            if mb:
+                n_el = mb * 1024 * 1024 // 2
+                w.view(-1)[:n_el].view(torch.int16).max()          # reads the bytes through the caches
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            _lib.check(lib.pgv_gemv(ctx.handle, _lib.dtype_code(dtype), 0, w.data_ptr(), x.data_ptr(), K, out.data_ptr(), N, N, K, B, _lib.stream_ptr()))
+            b.record(); b.synchronize()
+            ts.append(a.elapsed_time(b))
+        ts.sort()
+        print(f"prefetched {mb:3d} MB: gemv median {ts[len(ts) // 2] * 1e3:7.1f} us  min {ts[0] * 1e3:7.1f} us")
+
+
+if "prefetch" in sys.argv[1:]:
+    bench_prefetch(_lib.Context.get(0))
