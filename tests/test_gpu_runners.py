@@ -131,3 +131,61 @@ def test_qa_runner_end_to_end_matches_oracle(ctx, tmp_path):
         got = [int(t) for t in o["pred"].split()]
         k = next((i for i, m in enumerate(margins) if m < 0.02), NEW)           # compare up to the first near-tie of the oracle
         assert got[:k] == ref[:k], (n, got, ref, margins)
+
+
+def test_chat_interface_multi_turn_matches_oracle(ctx, tmp_path):
+    """VideoChatGPTInterface (reference chat.py): two turns on one clip.  The vision stage runs once per uploaded clip; every turn's
+    prompt is the reference's (first turn re-rooted on the conv_mode template, <video> replaced by the placeholder run once) and the
+    greedy answer equals the oracle's on the same prompt ids and pooled features."""
+    from video_llava_amd.chat import VideoChatGPTInterface
+    from video_llava_amd.model.video_chatgpt import VideoChatGPTConfig, VideoChatGPTLlamaForCausalLM, VisionConfig
+    from video_llava_amd.video_conversation import conv_templates
+    ccfg, lcfg = synth.CLIP_TINY, synth.LLAMA_TINY
+    cw = synth.make_clip_weights(ccfg, seed=41)
+    lw = synth.make_llama_weights(lcfg, seed=42, head_std=0.08)
+    tower = _tower(ccfg, cw)
+    calls = {"n": 0}
+    orig_call = type(tower).__call__
+
+    def counting_call(self, *a, **k):
+        calls["n"] += 1
+        return orig_call(self, *a, **k)
+    type(tower).__call__ = counting_call
+    try:
+        model = VideoChatGPTLlamaForCausalLM(VideoChatGPTConfig(vocab_size=lcfg.vocab, hidden_size=lcfg.hidden, intermediate_size=lcfg.inter,
+                                                                num_hidden_layers=lcfg.layers, num_attention_heads=lcfg.heads, eos_token_id=None,
+                                                                max_position_embeddings=4096),
+                                             VisionConfig(frame_size=ccfg.image), torch.float16)
+        model.load_state_dict(lw)
+        vc = model.get_model().vision_config
+        vc.vid_patch_token, vc.vid_start_token, vc.vid_end_token, vc.use_vid_start_end = lcfg.vocab - 3, lcfg.vocab - 2, lcfg.vocab - 1, True
+        tok = _Tok(lcfg.vocab)
+
+        class IP:
+            crop_size = {"height": ccfg.image, "width": ccfg.image}
+        P = (ccfg.image // ccfg.patch) ** 2
+        V = 100 + P
+        NEW = 5
+        chat = VideoChatGPTInterface("x", "y", components=(model, tower, tok, IP(), V), max_output_tokens=NEW, do_sample=False)
+        frames = synth.make_frames(7, ccfg.image, seed=9)
+        np.save(tmp_path / "clip.npy", frames)
+        chat.upload_video(str(tmp_path / "clip.npy"))
+        pooled = ovis.spatio_temporal_pool_torch(ovis.clip_select_features(ovis.clip_preprocess(frames), cw, ccfg))
+        replace = "<vid_start>" + "<vid_patch>" * V + "<vid_end>"
+        conv = conv_templates["pg-video-llava"].copy()
+        for turn, q in enumerate(["what is in the video?", "and then?"]):
+            chat.add_text(q, str(tmp_path / "clip.npy"))
+            got = chat.answer()
+            conv.append_message(conv.roles[0], (q + "\n<video>") if turn == 0 else q)
+            conv.append_message(conv.roles[1], None)
+            prompt = conv.get_prompt().replace("<video>", replace, 1)
+            ids = tok([prompt]).input_ids[0]
+            ref, margins = ollm.greedy_generate(lw, lcfg, ids, pooled.float(), lcfg.vocab - 2, lcfg.vocab - 1, lcfg.vocab - 3, NEW, return_margins=True)
+            k = next((i for i, m in enumerate(margins) if m < 0.02), NEW)
+            assert [int(t) for t in got.split()][:k] == ref[:k], (turn, got, ref, margins)
+            conv.messages[-1][-1] = got
+        assert calls["n"] == 1, "the CLIP tower must run once per uploaded clip, not once per turn"
+        chat.clear_history()
+        assert chat.video_features is None and chat.first_run
+    finally:
+        type(tower).__call__ = orig_call

@@ -1,0 +1,176 @@
+"""Interactive chat entry point with the reference's class, methods and CLI
+(video_chatgpt/chat.py:15-222 `VideoChatGPTInterface`, :336-367 `parse_args` / `__main__`).
+
+Same conversation state machine (add_text -> answer), same prompt assembly (`<video>` replaced by the placeholder run once, :129-130),
+same stop-string handling and post-processing.  Device work runs in libpgv.  Two deliberate differences:
+  * the reference re-runs the CLIP tower on the whole clip for EVERY turn (:137-144); here the pooled features of the uploaded clip
+    are computed once in `upload_video` and reused by every `answer()` of the conversation;
+  * `PGVideoLLaVA` (grounding: GroundingDINO / SAM / DEVA / RAM / OpenAI entity matching, :225-333) and the WhisperX transcript model are
+    side stacks outside the hot path: `--with_grounding` and `--use_asr` raise NotImplementedError.
+"""
+from __future__ import annotations
+
+import argparse
+
+import torch
+
+from .constants import DEFAULT_TRANSCRIPT_START, DEFAULT_VID_END_TOKEN, DEFAULT_VID_START_TOKEN, DEFAULT_VIDEO_PATCH_TOKEN
+from .model.utils import KeywordsStoppingCriteria
+from .video_conversation import SeparatorStyle, conv_templates, default_conversation
+
+
+class VideoChatGPTInterface:
+    def __init__(self, args_model_name, args_projection_path, use_asr=False, conv_mode="pg-video-llava", temperature=0.2,
+                 max_output_tokens=1024, components=None, do_sample=True) -> None:
+        if use_asr:
+            raise NotImplementedError("--use_asr needs the WhisperX transcript stack, which is outside this package's hot path")
+        self.use_asr = use_asr
+        self.conv_mode = conv_mode
+        if components is None:
+            from .eval.model_utils import initialize_model
+            components = initialize_model(args_model_name, args_projection_path)
+        model, vision_tower, tokenizer, image_processor, video_token_len = components
+        self.tokenizer, self.image_processor, self.vision_tower, self.model = tokenizer, image_processor, vision_tower, model
+        self.temperature = temperature
+        self.max_new_tokens = max_output_tokens
+        self.do_sample = do_sample
+        self.frame_size = (image_processor.crop_size["height"], image_processor.crop_size["width"])
+        if self.model.get_model().vision_config.use_vid_start_end:
+            self.replace_token = DEFAULT_VID_START_TOKEN + DEFAULT_VIDEO_PATCH_TOKEN * video_token_len + DEFAULT_VID_END_TOKEN
+        else:
+            self.replace_token = DEFAULT_VIDEO_PATCH_TOKEN * video_token_len
+        self.clear_history()
+
+    def clear_history(self):
+        self.state = default_conversation.copy()
+        self.video_features = None          # pooled [100 + P, 1024] features of the uploaded clip (computed once per clip)
+        self.video_path = None
+        self.video_frames = None
+        self.transcript_text = None
+        self.first_run = True
+
+    def upload_video(self, video_path):
+        """Decode + sample + resize the clip (reference :62-75) and run the vision stage ONCE for the whole conversation."""
+        from .feature_extraction import load_video
+        from .inference import video_features
+        if isinstance(video_path, str):
+            frames = load_video(video_path, shape=self.frame_size)
+        elif hasattr(video_path, "shape"):                 # uint8 [T, H, W, 3] frames handed over directly
+            frames = video_path
+        else:
+            raise NotImplementedError
+        self.video_path = video_path if isinstance(video_path, str) else None
+        self.video_frames = frames
+        self.video_features = video_features(frames, self.vision_tower, self.image_processor)
+        self.transcript_text = None
+
+    def add_text(self, text, video_path):
+        if len(text) <= 0 and video_path is None:
+            self.state.skip_next = True
+        text = text[:1536]                                   # hard cut-off (:93)
+        if self.first_run:
+            text = text[:1200]                               # hard cut-off for videos (:95)
+            if "<video>" not in text:
+                text = text + "\n<video>"
+            if self.use_asr:
+                text = text + "\n<audio_transcript>"
+            text = (text, video_path)
+            self.state = default_conversation.copy()
+        self.state.append_message(self.state.roles[0], text)
+        self.state.append_message(self.state.roles[1], None)
+        self.state.skip_next = False
+
+    def answer(self):
+        if self.state.skip_next:
+            return
+        if self.video_features is None:
+            raise RuntimeError("upload_video() first")
+        if self.first_run:                                   # re-root the first turn on the chosen template (:113-120)
+            curr_state = self.state
+            new_state = conv_templates[self.conv_mode].copy()
+            new_state.append_message(new_state.roles[0], curr_state.messages[-2][1])
+            new_state.append_message(new_state.roles[1], None)
+            self.state = new_state
+            self.first_run = False
+        prompt = self.state.get_prompt()
+        prompt = prompt.replace("<video>", self.replace_token, 1)
+        prompt = prompt.replace("<audio_transcript>", f'{DEFAULT_TRANSCRIPT_START}\n"{self.transcript_text}"', 1)
+        inputs = self.tokenizer([prompt])
+        input_ids = torch.as_tensor(inputs.input_ids)
+        stop_str = self.state.sep if self.state.sep_style != SeparatorStyle.TWO else self.state.sep2
+        stopping_criteria = KeywordsStoppingCriteria([stop_str], self.tokenizer, input_ids)
+        self.state.messages[-1][-1] = ""
+        with torch.inference_mode():
+            output_ids = self.model.generate(input_ids, video_spatio_temporal_features=self.video_features.unsqueeze(0),
+                                             do_sample=self.do_sample, temperature=float(self.temperature),
+                                             max_new_tokens=min(int(self.max_new_tokens), 1536), stopping_criteria=[stopping_criteria])
+        n_in = input_ids.shape[1]
+        n_diff = int((input_ids.to(output_ids.device) != output_ids[:, :n_in]).sum())
+        if n_diff > 0:
+            print(f"[Warning] {n_diff} output_ids are not the same as the input_ids")
+        outputs = self.tokenizer.batch_decode(output_ids[:, n_in:], skip_special_tokens=True)[0].strip()
+        if outputs.endswith(stop_str):
+            outputs = outputs[:-len(stop_str)]
+        output = self._post_process_code(outputs.strip())
+        self.state.messages[-1][-1] += output
+        return output
+
+    def interact(self):
+        print("Welcome to PG-Video-LLaVA !")
+        video_set = False
+        video_path = None
+        while True:
+            if not video_set:
+                video_path = input("Please enter the video file path:   ")
+                self.upload_video(video_path)
+                video_set = True
+            try:
+                text = input("USER>>")
+                if not text:
+                    print("----------\n\n")
+                    self.clear_history()
+                    video_set = False
+                    continue
+                self.add_text(text, video_path)
+                print("ASSISTANT>>", self.answer())
+            except KeyboardInterrupt:
+                print("----------")
+                print("QUITTING...")
+                return
+
+    def print_state(self):
+        txt = "SYSTEM: " + str(self.state.system) + "\n"
+        for role, msg in self.state.messages:
+            if type(msg) is tuple:
+                msg, _ = msg
+            txt += str(role) + ": " + str(msg) + "\n"
+        print(txt)
+
+    @staticmethod
+    def _post_process_code(code):
+        sep = "\n```"
+        if sep in code:
+            blocks = code.split(sep)
+            if len(blocks) % 2 == 1:
+                for i in range(1, len(blocks), 2):
+                    blocks[i] = blocks[i].replace("\\_", "_")
+            code = sep.join(blocks)
+        return code
+
+
+def parse_args(argv=None):
+    parser = argparse.ArgumentParser(description="Demo")
+    parser.add_argument("--model-name", type=str, required=True)
+    parser.add_argument("--projection_path", type=str, required=True)
+    parser.add_argument("--use_asr", action="store_true", help="Whether to use audio transcripts or not")
+    parser.add_argument("--conv_mode", type=str, required=False, default="pg-video-llava")
+    parser.add_argument("--with_grounding", action="store_true", help="Run with grounding module")
+    return parser.parse_args(argv)
+
+
+if __name__ == "__main__":
+    args = parse_args()
+    if args.with_grounding:
+        raise NotImplementedError("the grounding stack (GroundingDINO / SAM / DEVA / RAM) is outside this package's hot path")
+    VideoChatGPTInterface(args_model_name=args.model_name, args_projection_path=args.projection_path, use_asr=args.use_asr,
+                          conv_mode=args.conv_mode).interact()
