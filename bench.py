@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_MFMA_TFLOPS = 2500.0     # dense bf16/fp16, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0         # HBM3E spec, MI355X_MICROARCH.md
-VIT_FLOP_PER_FRAME_23L = 155.29e9     # SURVEY.md 8d (23 layers actually needed)
+VIT_FLOP_PER_FRAME_23L = {224: 155.29e9, 336: 366.0e9}     # 23 layers actually needed; 336 px: 577 tokens/frame
 
 
 def parse():
@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--new-tokens", type=int, default=256)
     ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16")
     ap.add_argument("--llm", choices=["7b", "13b"], default="7b")
+    ap.add_argument("--image", type=int, choices=[224, 336], default=224,
+                    help="336 = the LLaVA-1.5 variant the released PG-Video-LLaVA weights use: ViT-L/14-336 (577 tokens/frame), mlp2x_gelu projector, 676 video tokens")
     ap.add_argument("--weights", choices=["16bit", "fp8"], default="16bit",
                     help="fp8 = BASELINE config 5: decoder matrices quantised to e4m3 (per-row power-of-two scales) for the decode weight stream")
     ap.add_argument("--workload", choices=["full", "vision"], default="full",
@@ -155,17 +157,21 @@ def main():
     B, T, NEW = args.clips_per_gpu, args.frames, args.new_tokens
 
     # ---- models (random init on the device) ----------------------------------------------------------
-    tower = CLIPVisionTower(CLIPVisionTowerConfig(), dtype, dev)
-    ri.load_streaming(tower, ri.iter_clip_tensors(device=dev, dtype=dtype, seed=1))
+    S = args.image
+    video_rows = 100 + (S // 14) ** 2                      # 356 at 224 px, 676 at 336 px
+    projector = "linear" if S == 224 else "mlp2x_gelu"   # reference rule: model/video_chatgpt.py:52-55
+    tower = CLIPVisionTower(CLIPVisionTowerConfig(image_size=S), dtype, dev)
+    ri.load_streaming(tower, ri.iter_clip_tensors(image=S, device=dev, dtype=dtype, seed=1))
     shapes = dict(hidden=4096, inter=11008, layers=32, heads=32) if args.llm == "7b" else dict(hidden=5120, inter=13824, layers=40, heads=40)
     vocab = 32003
     model = None
     if args.workload == "full":
         cfg = VideoChatGPTConfig(vocab_size=vocab, hidden_size=shapes["hidden"], intermediate_size=shapes["inter"],
-                                 num_hidden_layers=shapes["layers"], num_attention_heads=shapes["heads"], eos_token_id=None)
-        model = VideoChatGPTLlamaForCausalLM(cfg, VisionConfig(frame_size=224), dtype, dev)
+                                 num_hidden_layers=shapes["layers"], num_attention_heads=shapes["heads"], eos_token_id=None,
+                                 mm_projector_type=projector)
+        model = VideoChatGPTLlamaForCausalLM(cfg, VisionConfig(frame_size=S), dtype, dev)
         ri.load_streaming(model, ri.iter_llama_tensors(vocab=vocab, hidden=shapes["hidden"], inter=shapes["inter"], layers=shapes["layers"],
-                                                       device=dev, dtype=dtype, seed=2))
+                                                       projector=projector, device=dev, dtype=dtype, seed=2))
         vc = model.get_model().vision_config
         vc.vid_patch_token, vc.vid_start_token, vc.vid_end_token, vc.use_vid_start_end = vocab - 3, vocab - 2, vocab - 1, True
         if args.weights == "fp8":
@@ -177,9 +183,9 @@ def main():
 
     # ---- synthetic inputs resident in HBM ------------------------------------------------------------
     gen = torch.Generator(device=dev).manual_seed(100 + rank)
-    frames = torch.randint(0, 256, (B * T, 224, 224, 3), dtype=torch.uint8, device=dev, generator=gen)
+    frames = torch.randint(0, 256, (B * T, S, S, 3), dtype=torch.uint8, device=dev, generator=gen)
     n_global = B * world
-    prompts_all = make_prompts(n_global, vocab, 356, seed=5)
+    prompts_all = make_prompts(n_global, vocab, video_rows, seed=5)
     mine = parallel.shard_indices(n_global, rank, world)
     prompts = [prompts_all[i] for i in mine]
 
@@ -225,7 +231,7 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = n_global * args.steps / elapsed
     vit_ms = sum(a.elapsed_time(b) for a, b in vit_events) / max(len(vit_events), 1)      # frames -> pooled features, per step
-    clip_feat_tflops = B * T * VIT_FLOP_PER_FRAME_23L / (vit_ms * 1e-3) / 1e12
+    clip_feat_tflops = B * T * VIT_FLOP_PER_FRAME_23L[S] / (vit_ms * 1e-3) / 1e12
 
     # ---- profiled pass: hipEvent pairs around every launch of each kernel family, on the launch stream -----------------
     fam = {}
@@ -271,13 +277,13 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "videos/sec (100x224^2 frames->answer)" if args.workload == "full" else "videos/sec (100x224^2 frames->projected video tokens)",
+            "metric": f"videos/sec (100x{S}^2 frames->answer)" if args.workload == "full" else f"videos/sec (100x{S}^2 frames->projected video tokens)",
             "value": value, "unit": "videos/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": ("BASELINE configs[2] batched as configs[3]: PG-Video-LLaVA-7B-shaped, "
-                                    f"{B} clips/GPU/step x {T} frames 224x224 -> ViT-L/14 (23 layers) -> pool -> linear projector -> "
-                                    f"prefill (~450 tok) -> {NEW} greedy tokens, random-init weights")
+                                    f"{B} clips/GPU/step x {T} frames {S}x{S} -> ViT-L/14 (23 layers) -> pool -> {projector} projector -> "
+                                    f"prefill (~{video_rows + 95} tok) -> {NEW} greedy tokens, random-init weights")
                        if args.workload == "full" else
                        f"BASELINE configs[1]: {B} clips/GPU/step x {T} frames -> ViT-L/14 (23 layers) + pool + Linear(1024,4096)",
                        "clips_per_gpu_per_step": B, "frames_per_clip": T, "new_tokens": NEW, "llm": args.llm if args.workload == "full" else None, "llm_weights": args.weights,
