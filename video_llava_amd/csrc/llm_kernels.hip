@@ -471,18 +471,20 @@ __global__ __launch_bounds__(256) void rms_resid_kernel(float* __restrict__ resi
 // ---------------------------------------------------------------------------------------------
 // decode attention: one workgroup of 8 waves per (sequence, head); lane = (key slot 0..3, 16-B d chunk 0..15), so a
 // wave-load covers 4 consecutive cache rows = 1 KiB contiguous.  Each lane keeps TWO independent online-softmax states
-// (keys k and k+32 of every 64-key round) and prefetches the next round, i.e. 8 x 16-B loads in flight per lane.
-// Applies RoPE to the fresh q/k, appends k/v to the cache at pos[b], attends over keys [0, pos]; the 64 partial states
-// are merged through LDS.
+// (keys k and k+32 of every 64-key round) with DEPTH rounds of loads in flight.
+// The kernel is latency-bound (60-76 MB of KV per launch over 256 workgroups, one per CU), so the fixed parts are kept off the
+// critical path: every lane builds its own slice of the rotated query straight from the qkv buffer (no LDS round trip, no
+// barrier before the key loop); the fresh token's k/v are appended to the cache by wave 0 on the side and enter the softmax from
+// registers (the loop only streams keys [0, pos)), so nothing waits for that store; partial states are merged inside each wave
+// with shuffles before 8 (not 64) states meet in LDS.
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(512) void decode_attn_kernel(const typename T::elem* __restrict__ qkv, const int* __restrict__ pos_arr,
                                                           const float2* __restrict__ rope, typename T::elem* __restrict__ Kc,
                                                           typename T::elem* __restrict__ Vc, typename T::elem* __restrict__ out, int H, int heads,
                                                           int max_seq, float scale_log2e) {
-    __shared__ float qs[HD];
-    __shared__ float st_m[64], st_l[64];
-    __shared__ float st_o[64][HD + 4];
+    __shared__ float st_m[8], st_l[8];
+    __shared__ float st_o[8][HD];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int h = blockIdx.x, b = blockIdx.y;
     const int pos = pos_arr[b];
@@ -491,86 +493,112 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(const typename T::elem
     const typename T::elem* v = q + 2 * H;
     typename T::elem* kcache = Kc + ((size_t)b * heads + h) * max_seq * HD;
     typename T::elem* vcache = Vc + ((size_t)b * heads + h) * max_seq * HD;
-    // fresh token: rotate q (-> LDS, rounded to the activation dtype like the prefill path), rotate k and append k, v
-    if (tid < 64) {
-        const float2 cs = rope[(size_t)pos * 64 + tid];
-        const float q1 = (float)q[tid], q2 = (float)q[tid + 64];
-        qs[tid] = (float)T::from_f32(q1 * cs.x - q2 * cs.y);
-        qs[tid + 64] = (float)T::from_f32(q2 * cs.x + q1 * cs.y);
-    } else if (tid < 128) {
-        const int j = tid - 64;
-        const float2 cs = rope[(size_t)pos * 64 + j];
-        const float k1 = (float)k[j], k2 = (float)k[j + 64];
-        kcache[(size_t)pos * HD + j] = T::from_f32(k1 * cs.x - k2 * cs.y);
-        kcache[(size_t)pos * HD + j + 64] = T::from_f32(k2 * cs.x + k1 * cs.y);
-    } else if (tid < 256) {
-        const int j = tid - 128;
-        vcache[(size_t)pos * HD + j] = v[j];
-    }
-    // the appended row is read back below by other waves of this workgroup: make the stores visible CU-wide first
-    __threadfence_block();
-    __syncthreads();
     const int slot = lane >> 4, dc = lane & 15;
-    float qr[8];
+
+    // rotate-half RoPE on this lane's 8 dims d = dc*8 + e of a 128-wide row x: d < 64: x[d] c[d] - x[d+64] s[d];  d >= 64: x[d] c[d-64] + x[d-64] s[d-64]
+    // (values rounded to the activation dtype like the prefill path writes them)
+    const int j0 = (dc & 7) * 8;                       // rope index of e = 0
+    float cs_c[8], cs_s[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) qr[e] = qs[dc * 8 + e] * scale_log2e;
+    for (int e = 0; e < 8; ++e) { const float2 cs = rope[(size_t)pos * 64 + j0 + e]; cs_c[e] = cs.x; cs_s[e] = dc < 8 ? -cs.y : cs.y; }
+    auto rotated = [&](const typename T::elem* x, float (&r)[8]) {
+        const typename T::v8 own = *(const typename T::v8*)(x + dc * 8), oth = *(const typename T::v8*)(x + (dc ^ 8) * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = (float)T::from_f32((float)own[e] * cs_c[e] + (float)oth[e] * cs_s[e]);
+    };
+    float qr[8];
+    rotated(q, qr);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qr[e] *= scale_log2e;
+
     float m[2] = {-1e30f, -1e30f}, l[2] = {0.f, 0.f}, o[2][8];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[u][e] = 0.f;
-    const int n_keys = pos + 1;
+    const int n_keys = pos;                            // cached keys; the fresh key (index pos) is handled from registers below
     const int key0 = w * 4 + slot;
-    // DEPTH rounds of 64 keys are kept in flight per workgroup (DEPTH x 4 x 16-B loads per lane): with one workgroup per CU and a
-    // ~2 us loaded HBM latency, two rounds (32 KiB per CU) sustain only ~3.5 TB/s over the chip; four rounds double that.
+    // DEPTH rounds of 64 keys are kept in flight per workgroup (DEPTH x 4 x 16-B loads per lane)
     constexpr int DEPTH = 4;
     typename T::v8 kq[DEPTH][2], vq[DEPTH][2];
     auto load = [&](int key, typename T::v8& kk_, typename T::v8& vv_) {
-        const int kc = min(key, n_keys - 1);               // clamped rows are masked below
+        const int kc = max(0, min(key, n_keys - 1));   // clamped rows are masked below
         kk_ = *(const typename T::v8*)(kcache + (size_t)kc * HD + dc * 8);
         vv_ = *(const typename T::v8*)(vcache + (size_t)kc * HD + dc * 8);
     };
+    auto update = [&](int u, const typename T::v8& kf, const typename T::v8& vf, bool valid) {
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += qr[e] * (float)kf[e];
+        s = row16_sum(s);
+        if (valid) {
+            const float mn = fmaxf(m[u], s);
+            const float alpha = exp2f(m[u] - mn), pv = exp2f(s - mn);
+            m[u] = mn;
+            l[u] = l[u] * alpha + pv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[u][e] = o[u][e] * alpha + pv * (float)vf[e];
+        }
+    };
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) { load(key0 + 64 * d, kq[d][0], vq[d][0]); load(key0 + 64 * d + 32, kq[d][1], vq[d][1]); }
+
+    // fresh token (overlaps the first loads): wave 0 appends the rotated k and v to the cache; its slot-0 lanes also keep them for the softmax
+    typename T::v8 knew, vnew;
+    if (w == 0) {
+        float kr[8];
+        rotated(k, kr);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) knew[e] = T::from_f32(kr[e]);
+        vnew = *(const typename T::v8*)(v + dc * 8);
+        if (slot == 0) {
+            *(typename T::v8*)(kcache + (size_t)pos * HD + dc * 8) = knew;
+            *(typename T::v8*)(vcache + (size_t)pos * HD + dc * 8) = vnew;
+        }
+    }
+
     for (int base = key0; base < n_keys; base += 64 * DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int key = base + 64 * d + 32 * u;
-                float s = 0.f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) s += qr[e] * (float)kq[d][u][e];
-                s = row16_sum(s);
-                if (key < n_keys) {
-                    const float mn = fmaxf(m[u], s);
-                    const float alpha = exp2f(m[u] - mn), pv = exp2f(s - mn);
-                    m[u] = mn;
-                    l[u] = l[u] * alpha + pv;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[u][e] = o[u][e] * alpha + pv * (float)vq[d][u][e];
-                }
-            }
+            for (int u = 0; u < 2; ++u) update(u, kq[d][u], vq[d][u], base + 64 * d + 32 * u < n_keys);
             // refill this ring slot with the round DEPTH ahead (clamped loads past the end are harmless and masked)
             load(base + 64 * (d + DEPTH), kq[d][0], vq[d][0]);
             load(base + 64 * (d + DEPTH) + 32, kq[d][1], vq[d][1]);
         }
     }
+    if (w == 0) update(0, knew, vnew, slot == 0);      // the fresh key, once (wave 0, slot 0)
+
+    // merge: the lane's two states, then the four slots of the wave (lanes with equal dc), then the eight waves through LDS
+    auto combine = [&](float& ma, float& la, float (&oa)[8], float mb, float lb, const float (&ob)[8]) {
+        const float mn = fmaxf(ma, mb);
+        const float fa = exp2f(ma - mn), fb = exp2f(mb - mn);
+        ma = mn; la = la * fa + lb * fb;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int sid = (w * 4 + slot) * 2 + u;
-        if (dc == 0) { st_m[sid] = m[u]; st_l[sid] = l[u]; }
+        for (int e = 0; e < 8; ++e) oa[e] = oa[e] * fa + ob[e] * fb;
+    };
+    combine(m[0], l[0], o[0], m[1], l[1], o[1]);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) st_o[sid][dc * 8 + e] = o[u][e];
+    for (int sh = 16; sh <= 32; sh <<= 1) {
+        float ob[8];
+        const float mb = __shfl_xor(m[0], sh, 64), lb = __shfl_xor(l[0], sh, 64);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ob[e] = __shfl_xor(o[0][e], sh, 64);
+        combine(m[0], l[0], o[0], mb, lb, ob);
+    }
+    if (slot == 0) {
+        if (dc == 0) { st_m[w] = m[0]; st_l[w] = l[0]; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) st_o[w][dc * 8 + e] = o[0][e];
     }
     __syncthreads();
     if (tid < HD) {
-        float M = -1e30f;
-#pragma unroll 8
-        for (int i = 0; i < 64; ++i) M = fmaxf(M, st_m[i]);
+        float M = st_m[0];
+#pragma unroll
+        for (int i = 1; i < 8; ++i) M = fmaxf(M, st_m[i]);
         float L = 0.f, acc = 0.f;
-#pragma unroll 8
-        for (int i = 0; i < 64; ++i) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
             const float f = exp2f(st_m[i] - M);
             L += st_l[i] * f;
             acc += st_o[i][tid] * f;
