@@ -150,6 +150,8 @@ def main():
     rank, world, local = parallel.init_distributed()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if os.environ.get("PGV_BENCH_SHARE_DEVICE"):        # control-flow smoke test of the N > 1 path on a 1-GPU box (with PGV_DIST_BACKEND=gloo)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
@@ -196,7 +198,7 @@ def main():
 
     vit_events = []
 
-    def step(new_tokens):
+    def step(new_tokens, collate=True):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()                                   # torch's current stream IS the stream libpgv launches on
         pooled = vision(frames)
@@ -208,6 +210,8 @@ def main():
                              eos_token_id=None, chunk=64)
         toks = torch.stack([out[b, len(prompts[b]):len(prompts[b]) + new_tokens] for b in range(B)]).to(torch.int32)
         lens = torch.full((B,), new_tokens, dtype=torch.int32, device=dev)
+        if not collate:                               # rank-0-only profiled pass: no collective (the other ranks are not in it)
+            return toks
         return parallel.gather_answers(toks, lens, n_global, rank, world)
 
     def barrier():
@@ -239,7 +243,7 @@ def main():
     if rank == 0 and not args.no_profile_pass:
         prof_tokens = min(NEW, 9)
         ctx.prof_enable(True); ctx.prof_reset()
-        step(prof_tokens)
+        step(prof_tokens, collate=False)
         torch.cuda.synchronize(dev)
         raw = ctx.prof_get()
         ctx.prof_enable(False)

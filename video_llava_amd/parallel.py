@@ -23,7 +23,7 @@ def init_distributed(backend: str | None = None) -> tuple[int, int, int]:
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("PGV_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
@@ -53,6 +53,8 @@ def gather_answers(tokens: torch.Tensor, lengths: torch.Tensor, n_items: int, ra
     assert cap == shard_capacity(n_items, world) and lengths.shape == (cap,)
     if world > 1:
         packed = torch.cat([tokens.reshape(-1), lengths]).contiguous()
+        if dist.get_backend() == "gloo":                    # CPU tests and the shared-device bench smoke test: stage through the host
+            packed = packed.cpu()
         out = torch.empty(world * packed.numel(), dtype=packed.dtype, device=packed.device)
         dist.all_gather_into_tensor(out, packed)
         out = out.view(world, -1).cpu()
