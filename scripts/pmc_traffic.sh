@@ -9,10 +9,4 @@ ARGS="--steps 1 --warmup 0 --new-tokens 9 --no-cpu-baseline --no-profile-pass"
 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/pmc/fetch -o pmc -- python bench.py $ARGS > gpurun_out/pmc/fetch.json 2> gpurun_out/pmc/fetch.err
 timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/pmc/write -o pmc -- python bench.py $ARGS > gpurun_out/pmc/write.json 2> gpurun_out/pmc/write.err
 ls -la gpurun_out/pmc/fetch gpurun_out/pmc/write
-python - <<'PY'
-import sqlite3, glob
-for d in ("fetch", "write"):
-    for db in glob.glob(f"gpurun_out/pmc/{d}/*.db"):
-        c = sqlite3.connect(db)
-        print(db, [r[0] for r in c.execute("select name from sqlite_master where type in ('table','view')").fetchall()])
-PY
+python scripts/pmc_summary.py gpurun_out/pmc/fetch/pmc_results.db gpurun_out/pmc/write/pmc_results.db gpurun_out/pmc/pmc_traffic.json | head -30
