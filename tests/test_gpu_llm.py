@@ -276,3 +276,41 @@ def test_llm_fp8_weights_vs_oracle(ctx, golden_dir, dtype, tol):
         nxt, lg = m.decode_step(kv, nxt, want_logits=True)
         nxt2, lg2 = m2.decode_step(kv2, nxt2, want_logits=True)
         assert torch.equal(lg, lg2) and torch.equal(nxt, nxt2)
+
+
+@pytest.mark.parametrize("weights", ["bf16", "fp8"])
+def test_full_7b_batch_invariance(ctx, weights):
+    """BASELINE size (PG-Video-LLaVA-7B shapes: 32 layers, hidden 4096, 356 video tokens), size-independent property: the data-parallel
+    unit is one clip, so a clip's greedy answer and its logits must not depend on which other clips share the GPU batch.  Every kernel on
+    the path computes a sequence's rows / columns independently of the others, so the match is bitwise -- with 16-bit and with fp8 weights."""
+    from video_llava_amd import random_init as ri
+    from video_llava_amd.model.video_chatgpt import VideoChatGPTConfig, VideoChatGPTLlamaForCausalLM, VisionConfig
+    vocab = 32003
+    cfg = VideoChatGPTConfig(vocab_size=vocab, hidden_size=4096, intermediate_size=11008, num_hidden_layers=32, num_attention_heads=32, eos_token_id=None)
+    m = VideoChatGPTLlamaForCausalLM(cfg, VisionConfig(frame_size=224), torch.bfloat16, torch.device(DEV))
+    ri.load_streaming(m, ri.iter_llama_tensors(vocab=vocab, hidden=4096, inter=11008, layers=32, device=DEV, dtype=torch.bfloat16, seed=11))
+    vc = m.get_model().vision_config
+    vc.vid_patch_token, vc.vid_start_token, vc.vid_end_token, vc.use_vid_start_end = vocab - 3, vocab - 2, vocab - 1, True
+    if weights == "fp8":
+        m.quantize_weights_fp8()
+    rng = np.random.default_rng(1)
+    V = 356
+    prompts = [[1] + rng.integers(3, vocab - 3, 60 + extra).tolist() + [vocab - 2] + [vocab - 3] * V + [vocab - 1] + rng.integers(3, vocab - 3, 6).tolist()
+               for extra in (0, 17, 5)]
+    feats = torch.from_numpy(rng.standard_normal((3, V, 1024)).astype(np.float32) * 0.5).to(torch.float16).to(DEV)
+    n = 6
+    kv, nxt_b, lg_b = m.prefill(prompts, feats, 512, want_logits=True)
+    steps_b = [(nxt_b.clone(), lg_b.clone())]
+    for _ in range(n - 1):
+        nxt_b, lg_b = m.decode_step(kv, nxt_b, want_logits=True)
+        steps_b.append((nxt_b.clone(), lg_b.clone()))
+    del kv
+    for i, p in enumerate(prompts):
+        kv1, nxt, lg = m.prefill([p], feats[i:i + 1], 512, want_logits=True)
+        for t in range(n):
+            assert torch.equal(lg[0], steps_b[t][1][i]), (weights, i, t)
+            assert int(nxt[0]) == int(steps_b[t][0][i])
+            if t + 1 < n:
+                nxt, lg = m.decode_step(kv1, nxt, want_logits=True)
+        del kv1
+    assert torch.isfinite(steps_b[-1][1]).all()
