@@ -326,13 +326,30 @@ __global__ __launch_bounds__(512) void gemv_mfma_kernel(GemvArgs p) {
                     acc[t] = T::mfma16(fp8x8_to_v8<T>(wr[u][t][2], wr[u][t][3]), xf[u][1], acc[t]);
                 }
         }
-        for (; j < j_end; j += 8) {
-            const typename T::v8 x0 = *(const typename T::v8*)(xp + (size_t)(2 * j) * 64), x1 = *(const typename T::v8*)(xp + (size_t)(2 * j + 1) * 64);
+        if (j < j_end) {
+            // Ragged tail (11008 / 2 splits / 8 waves = 10.75 groups per wave): ONE more branch-free batch. Groups past the end re-read the
+            // last valid group (an L2 hit) against an all-zero x fragment, which adds exact zeros; predicated loads would make hipcc
+            // serialise the whole batch (a vmcnt(0) per load), and one load per round trip is what this replaces.
+            u32x4_t wr[U - 1][TILES];
+            typename T::v8 xf[U - 1][2];
 #pragma unroll
-            for (int t = 0; t < TILES; ++t) {
-                const u32x4_t wr = __builtin_nontemporal_load((const u32x4_t*)(wp[t] + (size_t)j * 1024));
-                acc[t] = T::mfma16(fp8x8_to_v8<T>(wr[0], wr[1]), x0, acc[t]);
-                acc[t] = T::mfma16(fp8x8_to_v8<T>(wr[2], wr[3]), x1, acc[t]);
+            for (int u = 0; u < U - 1; ++u) {
+                const int jj = min(j + 8 * u, j_end - 1);
+#pragma unroll
+                for (int t = 0; t < TILES; ++t) wr[u][t] = __builtin_nontemporal_load((const u32x4_t*)(wp[t] + (size_t)jj * 1024));
+                xf[u][0] = *(const typename T::v8*)(xp + (size_t)(2 * jj) * 64);
+                xf[u][1] = *(const typename T::v8*)(xp + (size_t)(2 * jj + 1) * 64);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < U - 1; ++u) {
+                const bool live = j + 8 * u < j_end;
+                const typename T::v8 z = {};
+#pragma unroll
+                for (int t = 0; t < TILES; ++t) {
+                    acc[t] = T::mfma16(fp8x8_to_v8<T>(wr[u][t][0], wr[u][t][1]), live ? xf[u][0] : z, acc[t]);
+                    acc[t] = T::mfma16(fp8x8_to_v8<T>(wr[u][t][2], wr[u][t][3]), live ? xf[u][1] : z, acc[t]);
+                }
             }
         }
     } else {
@@ -365,19 +382,27 @@ __global__ __launch_bounds__(512) void gemv_mfma_kernel(GemvArgs p) {
                     acc[t] = T::mfma16(wf[u][1][t], xf[u][1], acc[t]);
                 }
         }
-        for (; j < j_end; j += 8) {
+        if (j < j_end) {                            // ragged tail as in the fp8 branch; here the last group may also hold a single 32-block
+            typename T::v8 wf[U][2][TILES], xf[U][2];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int kb = 2 * j + h;
-                if (kb < kb_end) {
-                    const typename T::v8 xf = *(const typename T::v8*)(xp + (size_t)kb * 64);
+            for (int u = 0; u < U; ++u)
 #pragma unroll
-                    for (int t = 0; t < TILES; ++t) {
-                        const typename T::v8 wf = __builtin_nontemporal_load((const typename T::v8*)(wp[t] + (size_t)kb * 1024));
-                        acc[t] = T::mfma16(wf, xf, acc[t]);
-                    }
+                for (int h = 0; h < 2; ++h) {
+                    const size_t kb = (size_t)min(2 * (j + 8 * u) + h, kb_end - 1);
+#pragma unroll
+                    for (int t = 0; t < TILES; ++t) wf[u][h][t] = __builtin_nontemporal_load((const typename T::v8*)(wp[t] + kb * 1024));
+                    xf[u][h] = *(const typename T::v8*)(xp + kb * 64);
                 }
-            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const bool live = 2 * (j + 8 * u) + h < kb_end;
+                    const typename T::v8 z = {};
+#pragma unroll
+                    for (int t = 0; t < TILES; ++t) acc[t] = T::mfma16(wf[u][h][t], live ? xf[u][h] : z, acc[t]);
+                }
         }
     }
 #pragma unroll
