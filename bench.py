@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--workload", choices=["full", "vision"], default="full",
                     help="full = BASELINE config 3/4 (frames -> answer); vision = config 2 (ViT + pool + projector)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-frames", action="store_true",
+                    help="additionally time the same steps with the uint8 frames uploaded from pinned host memory inside the timed region "
+                         "(reported as pcie_inclusive; `value` always has the frames resident in HBM)")
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=4)
     ap.add_argument("--cpu-layers", type=int, default=2)
@@ -198,10 +201,10 @@ def main():
 
     vit_events = []
 
-    def step(new_tokens, collate=True):
+    def step(new_tokens, collate=True, host_frames=None):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()                                   # torch's current stream IS the stream libpgv launches on
-        pooled = vision(frames)
+        pooled = vision(frames if host_frames is None else host_frames.to(dev, non_blocking=True))
         e1.record()
         vit_events.append((e0, e1))
         if args.workload == "vision":
@@ -235,6 +238,22 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = n_global * args.steps / elapsed
     vit_ms = sum(a.elapsed_time(b) for a, b in vit_events) / max(len(vit_events), 1)      # frames -> pooled features, per step
+    pcie = None
+    if args.host_frames:                              # same steps, frames handed over as host buffers (the reference's boundary: PIL images on the host)
+        host = frames.cpu().pin_memory()
+        step(NEW, host_frames=host)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step(NEW, host_frames=host)
+        barrier()
+        el = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            el = float(tt[0])
+        pcie = {"value": n_global * args.steps / el, "unit": "videos/sec", "ms_per_step": el / args.steps * 1e3,
+                "h2d_bytes_per_step_per_gpu": int(host.numel())}
     clip_feat_tflops = B * T * VIT_FLOP_PER_FRAME_23L[S] / (vit_ms * 1e-3) / 1e12
 
     # ---- profiled pass: hipEvent pairs around every launch of each kernel family, on the launch stream -----------------
@@ -296,6 +315,8 @@ def main():
             "clip_feat_tflops": clip_feat_tflops, "clip_feat_frac_of_mfma_peak": clip_feat_tflops / PEAK_MFMA_TFLOPS,
             "clip_feat_ms_per_step": vit_ms,
         }
+        if pcie:
+            line["pcie_inclusive"] = pcie
         if fam:
             line["families"] = fam
         if roofline:
