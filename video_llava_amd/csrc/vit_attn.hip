@@ -2,18 +2,22 @@
 // eager math :259-277): per frame and head, softmax(q k^T * d^-0.5) v with N = patches+1 tokens, d = 64, no mask,
 // softmax in fp32.
 //
-// One workgroup per (frame, head).  The whole K [Npad,64] and V^T [64,Npad] of that head live in LDS
-// (73 KiB at N=257 -> two workgroups per CU), each wave owns 32-query blocks.  Both products run on
-// v_mfma_f32_32x32x16 with *swapped* operands so that a lane owns one query column throughout:
+// One workgroup per (frame, head).  The whole K and V [Npad,64] of that head live in LDS, both ROW-major and both staged by
+// LDS-DMA (global_load_lds, 16-B chunks XOR-swizzled through the source address; 72 KiB at N=257 -> two workgroups per CU);
+// each wave owns 32-query blocks.  Both products run on v_mfma_f32_32x32x16 with *swapped* operands so that a lane owns one
+// query column throughout:
 //   S^T[key, q]  = K[key,:] . Q[q,:]      (A = K fragment from LDS, B = Q fragment held in registers)
-//   O^T[d, q]   += V^T[d, keys] . P^T[keys, q]   (A = V^T fragment from LDS, B = P packed from the S registers)
+//   O^T[d, q]   += V^T[d, keys] . P^T[keys, q]   (A = V^T fragment, B = P packed from the S registers)
 // so row max / row sum are lane-local plus one cross-half shuffle, and the probabilities never leave registers.
-// The S accumulator's key order inside a 16-key group is {0-3, 8-11 | 4-7, 12-15} per half-wave; V^T is written to
-// LDS with key bits 2 and 3 swapped so each lane's 8 k-slots are one contiguous ds_read_b128.
-// K rows are DMA'd with global_load_lds (XOR-swizzled via the source address, as in gemm.hip); V is transposed
-// through registers with ds_write_b16 (1/9 of a workgroup's LDS traffic).  Keys are processed in chunks of 96 with an
-// online softmax so the same kernel covers N=257 (224 px) and N=577 (336 px).
+// The V^T fragments come from the row-major V image through gfx950's transposing LDS read (ds_read_b64_tr_b16: a 16-lane group
+// reads a [4 keys][16 d] block, every lane supplying the address of 4 consecutive d of one key and receiving 4 consecutive keys
+// of one d).  The S accumulator's key order inside a 16-key group is {0-3, 8-11 | 4-7, 12-15} per half-wave, which is exactly
+// two such 4-key reads per lane.  (Round 1 first transposed V through registers with ds_write_b16: 8-way bank conflicts on the
+// writes -- SQ_LDS_BANK_CONFLICT was 48 % of SQ_LDS_IDX_ACTIVE -- and 40 VGPRs of staging buffers.)
+// Keys are processed in chunks of 96 with an online softmax so the same kernel covers N=257 (224 px) and N=577 (336 px).
 #include <stdlib.h>
+
+#include <type_traits>
 
 #include "pgv_common.h"
 
@@ -21,6 +25,7 @@ namespace {
 
 constexpr int HD = 64;        // CLIP-L head_dim
 constexpr int CB = 3;         // key blocks (of 32) per online-softmax chunk
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
 
 struct AttnArgs {
     const char* qkv;   // [T*N, ld] 16-bit: q at col 0, k at col C, v at col 2C (fused qkv GEMM output)
@@ -28,12 +33,12 @@ struct AttnArgs {
     int ld, ldo;
     int N, C, heads;
     int nkb;           // ceil(N/32)
-    int vt_stride;     // bytes per V^T row in LDS (Npad*2 + 16: odd multiple of 16 -> conflict-free b128 reads)
     float scale_log2e; // d^-0.5 * log2(e)
-    int abl;           // diagnostic ablation (PGV_ATTN_ABLATE): 1 = no V staging, 2 = no query loop, 4 = no K staging
+    int abl;           // diagnostic ablation (PGV_ATTN_ABLATE): 1 = no V staging, 2 = no query loop, 4 = no K staging,
+                       // 8 = no exp (copy), 16 = no PV MFMAs, 32 = no S MFMAs, 64 = no max, 128 = static block assignment (wrong results for 8..64)
 };
 
-template <typename T>
+template <typename T, int ABL>
 __global__ __launch_bounds__(256) void vit_attn_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -42,66 +47,21 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(AttnArgs p) {
     const int t = blockIdx.x / p.heads, h = blockIdx.x - t * p.heads;
     const int N = p.N, npad = p.nkb * 32;
     char* Ks = smem;                               // [npad][128 B], chunk-swizzled
-    char* Vt = smem + (size_t)npad * 128;          // [64][vt_stride]
-    int* qctr = (int*)(Vt + (size_t)HD * p.vt_stride);   // next unassigned query block
+    char* Vs = smem + (size_t)npad * 128;          // [npad][128 B], chunk bit 2 flipped on rows with (row >> 1) & 1
+    int* qctr = (int*)(Vs + (size_t)npad * 128);   // next unassigned query block
     if (tid == 0) *qctr = nw;
     const size_t row0 = (size_t)t * N;
     const char* kbase = p.qkv + ((size_t)p.C + h * HD) * 2;
     const char* vbase = p.qkv + ((size_t)2 * p.C + h * HD) * 2;
     const char* qbase = p.qkv + ((size_t)h * HD) * 2;
 
-    // ---- stage K: one wave-instruction = 8 rows x 128 B, destination linear, source chunk pre-swizzled ----
-    if (!(p.abl & 4)) {
-        const int srow = lane >> 3, slot = lane & 7;
-        for (int g = w; g < npad / 8; g += nw) {
-            const int row = g * 8 + srow;
-            const int chunk = slot ^ ((row >> 1) & 7);
-            const int rr = min(row, N - 1);
-            const char* src = kbase + ((row0 + rr) * p.ld + chunk * 8) * 2;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(Ks + g * 1024), 16, 0, 0);
-        }
-    }
-    // ---- stage V transposed: thread takes (key, 8-wide d chunk), writes 8 halfwords to Vt[d][pos(key)] ----
-    // All global loads of a batch are issued before the first LDS write: one exposed round trip per batch instead of one per
-    // element (the loop was 12 dependent load -> 8 x ds_write_b16 rounds and dominated the kernel).
-    if (!(p.abl & 1)) {
-        constexpr int VB = 10;                                     // loads in flight per thread (40 VGPRs)
-        const int total = npad * 8;
-        for (int base = tid; base < total; base += VB * blockDim.x) {
-            typename T::v8 vv[VB];
-#pragma unroll
-            for (int u = 0; u < VB; ++u) {
-                const int idx = base + u * blockDim.x;
-                const int key = min(idx >> 3, N - 1), dc = idx & 7;
-                vv[u] = *(const typename T::v8*)(vbase + ((row0 + key) * p.ld + dc * 8) * 2);
-            }
-#pragma unroll
-            for (int u = 0; u < VB; ++u) {
-                const int idx = base + u * blockDim.x;
-                if (idx < total) {
-                    const int key = idx >> 3, dc = idx & 7;
-                    const int pos = (key & ~12) | ((key & 4) << 1) | ((key & 8) >> 1);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        *(typename T::elem*)(Vt + (size_t)(dc * 8 + e) * p.vt_stride + pos * 2) = (key < N) ? vv[u][e] : (typename T::elem)0.0f;
-                }
-            }
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
     const int l31 = lane & 31, hi = lane >> 5;
-    const int sw = (lane >> 1) & 7;
-    int koffs[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) koffs[kk] = ((kk * 2 + hi) ^ sw) << 4;
-    const float NEG = -1e30f;            // raw-score domain: NEG * scale is still hugely negative, exp2 -> 0
-
-    // Query blocks of 32 are handed out dynamically through an LDS counter: the kernel is bound by the softmax VALU work, a CU runs
-    // two workgroups (8 waves on 4 SIMDs) and a static split of 9 blocks over the waves left whole SIMDs idle at the tail.
-    // Q fragments (B operand): lane (q = l31, hi) holds Q[q][kk*16 + hi*8 .. +8]; the next block's are fetched during this one's work.
+    // Query blocks of 32 are handed out dynamically through an LDS counter: a CU runs two workgroups (8 waves on 4 SIMDs) and a static
+    // split of 9 blocks over the waves left whole SIMDs idle at the tail.
+    // Q fragments (B operand): lane (q = l31, hi) holds Q[q][kk*16 + hi*8 .. +8].  The first block's are requested before the K/V
+    // staging and every later block's one block ahead, and each block ends with an explicit vmcnt(0) BEFORE its output stores are
+    // issued: hipcc sizes the vmcnt in front of the first MFMA for the loop-entry path (4 younger loads), which on the back edge also
+    // drained the 8 output stores issued in between.
     auto load_q = [&](int qb, typename T::v8 (&dst)[4]) {
         const int qrow = min(qb * 32 + l31, N - 1);
 #pragma unroll
@@ -112,10 +72,141 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(AttnArgs p) {
         if (lane == 0) v = atomicAdd(qctr, 1);
         return __builtin_amdgcn_readfirstlane(v);
     };
-    const int nblocks = (p.abl & 2) ? 0 : p.nkb;
     typename T::v8 qnext[4];
+    load_q(w, qnext);
+
+    // ---- stage K and V: one wave-instruction = 8 rows x 128 B, destination linear, source chunk pre-swizzled.  K: chunk ^ ((row >> 1) & 7)
+    // (conflict-free ds_read_b128 of one row per lane); V: chunk ^ (((row >> 1) & 1) << 2) (conflict-free transposing reads: the 32 lanes of
+    // an LDS cycle touch 4 consecutive keys x 64 B, and rows two apart share banks).  Rows past N re-read the last row: their
+    // probabilities are exactly 0 and the duplicated V values are finite.
+    {
+        const int srow = lane >> 3, slot = lane & 7;
+        for (int g = w; g < npad / 8; g += nw) {
+            const int row = g * 8 + srow;
+            const int rr = min(row, N - 1);
+            if (!(p.abl & 4)) {
+                const int chunk = slot ^ ((row >> 1) & 7);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + ((row0 + rr) * p.ld + chunk * 8) * 2),
+                                                 (__attribute__((address_space(3))) void*)(Ks + g * 1024), 16, 0, 0);
+            }
+            if (!(p.abl & 1)) {
+                const int chunk = slot ^ (((row >> 1) & 1) << 2);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + ((row0 + rr) * p.ld + chunk * 8) * 2),
+                                                 (__attribute__((address_space(3))) void*)(Vs + g * 1024), 16, 0, 0);
+            }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): K / V DMA and the first Q fragments
+    __syncthreads();
+
+    const int sw = (lane >> 1) & 7;
+    int koffs[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) koffs[kk] = ((kk * 2 + hi) ^ sw) << 4;
+    // transposing V reads: lane i of a 16-lane group g addresses key (4 hi + i/4) of the 16-key slice, d columns jj*32 + g*16 + (i%4)*4 .. +3
+    const int li = lane & 15, lg = (lane >> 4) & 1;
+    const int voff0 = (4 * hi + (li >> 2)) * 128 + (((lg * 2 + ((li & 3) >> 1)) ^ (((li >> 3) & 1) << 2)) << 4) + (li & 1) * 8;   // jj = 1: ^ 64
+    const float NEG = -1e30f;            // raw-score domain: NEG * scale is still hugely negative, exp2 -> 0
+
+    // S^T of one chunk: key blocks past the end re-read the last one (valid LDS, masked in the softmax) so there are no branches, the 12
+    // fragment reads are issued together and the MFMAs of the three independent accumulators interleave.
+    auto scores = [&](int kb0, const typename T::v8 (&qf)[4], f32x16_t (&s)[CB]) __attribute__((always_inline)) {
+        typename T::v8 kf[CB][4];
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+            const char* kr = Ks + (size_t)(min(kb0 + c, p.nkb - 1) * 32 + l31) * 128;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) kf[c][kk] = *(const typename T::v8*)(kr + koffs[kk]);
+        }
+#pragma unroll
+        for (int c = 0; c < CB; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[c][e] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int c = 0; c < CB; ++c) {
+                if constexpr ((ABL & 32) != 0) { s[c][kk] += (float)kf[c][kk][0] * (float)qf[kk][0]; continue; }
+                s[c] = T::mfma32(kf[c][kk], qf[kk], s[c]);
+            }
+    };
+    // Online-softmax update with one chunk of scores and O^T += V^T . P^T.  MASK: the chunk may hold keys >= N.
+    auto absorb = [&](int kb0, f32x16_t (&s)[CB], f32x16_t (&o)[2], float& mrun, float& lrun, auto mask_tag) __attribute__((always_inline)) {
+        constexpr bool MASK = decltype(mask_tag)::value;
+        // V^T fragments of the chunk: issued first, their LDS latency hides under the softmax arithmetic
+        typename T::v8 vf[CB][2][2];
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+            const char* vb = Vs + (size_t)min(kb0 + c, p.nkb - 1) * 4096;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const char* a0 = vb + (voff0 ^ (j * 64)) + ks * 2048;
+                    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)a0);
+                    const s16x4_t up = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(a0 + 1024));
+                    vf[c][ks][j] = __builtin_bit_cast(typename T::v8, __builtin_shufflevector(lo, up, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+        }
+        if constexpr (MASK) {
+#pragma unroll
+            for (int c = 0; c < CB; ++c) {
+                if ((kb0 + c + 1) * 32 > N) {                    // wave-uniform: only blocks that hold padding pay for the compares
+                    const int kbase_idx = (kb0 + c) * 32 + 4 * hi;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int key = kbase_idx + (e & 3) + 8 * (e >> 2);
+                        s[c][e] = (key < N) ? s[c][e] : NEG;     // also covers kb0+c >= nkb (key >= npad >= N)
+                    }
+                }
+            }
+        }
+        float cmax = NEG;
+        if constexpr ((ABL & 64) != 0) cmax = s[0][0];
+        else {
+#pragma unroll
+            for (int c = 0; c < CB; ++c)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) cmax = fmaxf(cmax, s[c][e]);
+            cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+        }
+        const float mnew = fmaxf(mrun, cmax * p.scale_log2e);
+        const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+        mrun = mnew;
+        // p = exp2(s * scale - m): one packed FMA per two scores, packed partial sums
+        const f32x2_t sc2 = {p.scale_log2e, p.scale_log2e}, nm2 = {-mnew, -mnew};
+        f32x2_t psum2 = {0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < CB; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+                const f32x2_t x = f32x2_t{s[c][e], s[c][e + 1]} * sc2 + nm2;
+                const f32x2_t pv = ((ABL & 8) != 0) ? x : f32x2_t{__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+                s[c][e] = pv[0]; s[c][e + 1] = pv[1];
+                psum2 += pv;
+            }
+        lrun = lrun * alpha + (psum2[0] + psum2[1]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[j][e] *= alpha;
+#pragma unroll
+        for (int c = 0; c < CB; ++c)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                typename T::v8 pa;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pa[e] = T::from_f32(s[c][ks * 8 + e]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if constexpr ((ABL & 16) != 0) { o[j][ks] += (float)vf[c][ks][j][0] * (float)pa[0]; continue; }
+                    o[j] = T::mfma32(vf[c][ks][j], pa, o[j]);
+                }
+            }
+    };
+
+    const int nblocks = (p.abl & 2) ? 0 : p.nkb;
     int qb = w, qb_next = next_block();
-    load_q(qb, qnext);
     for (; qb < nblocks; qb = qb_next, qb_next = next_block()) {
         typename T::v8 qf[4];
 #pragma unroll
@@ -129,88 +220,17 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(AttnArgs p) {
             for (int e = 0; e < 16; ++e) o[j][e] = 0.f;
         float mrun = NEG, lrun = 0.f;
 
-        for (int kb0 = 0; kb0 < p.nkb; kb0 += CB) {
-            // A key block past the end re-reads the last one (valid LDS) and is masked below: no branches, so the 12 fragment reads
-            // of a chunk are issued together and the MFMAs of the three independent accumulators interleave (the first version
-            // ran ds_read -> wait -> dependent MFMA one at a time and was latency-bound at ~180 cycles per MFMA).
-            int kb[CB];
-#pragma unroll
-            for (int c = 0; c < CB; ++c) kb[c] = min(kb0 + c, p.nkb - 1);
-            typename T::v8 kf[CB][4];
-#pragma unroll
-            for (int c = 0; c < CB; ++c) {
-                const char* kr = Ks + (size_t)(kb[c] * 32 + l31) * 128;
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) kf[c][kk] = *(const typename T::v8*)(kr + koffs[kk]);
-            }
-            f32x16_t s[CB];
-#pragma unroll
-            for (int c = 0; c < CB; ++c)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) s[c][e] = 0.f;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int c = 0; c < CB; ++c) s[c] = T::mfma32(kf[c][kk], qf[kk], s[c]);
-            // V^T fragments of the chunk: issued now, their LDS latency hides under the softmax arithmetic
-            typename T::v8 vf[CB][2][2];
-#pragma unroll
-            for (int c = 0; c < CB; ++c)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        vf[c][ks][j] = *(const typename T::v8*)(Vt + (size_t)(j * 32 + l31) * p.vt_stride + (kb[c] * 32 + ks * 16 + hi * 8) * 2);
-            // chunk max on the raw scores (scale > 0), padded keys masked only in the chunk that holds them (wave-uniform test)
-            if ((kb0 + CB) * 32 > N) {
-#pragma unroll
-                for (int c = 0; c < CB; ++c) {
-                    const int kbase_idx = (kb0 + c) * 32 + 4 * hi;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int key = kbase_idx + (e & 3) + 8 * (e >> 2);
-                        s[c][e] = (key < N) ? s[c][e] : NEG;     // also covers kb0+c >= nkb (key >= npad >= N)
-                    }
-                }
-            }
-            float cmax = NEG;
-#pragma unroll
-            for (int c = 0; c < CB; ++c)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) cmax = fmaxf(cmax, s[c][e]);
-            cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
-            const float mnew = fmaxf(mrun, cmax * p.scale_log2e);
-            const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
-            mrun = mnew;
-            // p = exp2(s * scale - m): one packed FMA per two scores, packed partial sums
-            const f32x2_t sc2 = {p.scale_log2e, p.scale_log2e}, nm2 = {-mnew, -mnew};
-            f32x2_t psum2 = {0.f, 0.f};
-#pragma unroll
-            for (int c = 0; c < CB; ++c)
-#pragma unroll
-                for (int e = 0; e < 16; e += 2) {
-                    const f32x2_t x = f32x2_t{s[c][e], s[c][e + 1]} * sc2 + nm2;
-                    const f32x2_t pv = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
-                    s[c][e] = pv[0]; s[c][e + 1] = pv[1];
-                    psum2 += pv;
-                }
-            lrun = lrun * alpha + (psum2[0] + psum2[1]);
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) o[j][e] *= alpha;
-            // O^T += V^T . P^T
-#pragma unroll
-            for (int c = 0; c < CB; ++c)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    typename T::v8 pa;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) pa[e] = T::from_f32(s[c][ks * 8 + e]);
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) o[j] = T::mfma32(vf[c][ks][j], pa, o[j]);
-                }
+        // (Issuing the scores of chunk i+1 beside the softmax of chunk i was tried: same time, 48 more VGPRs.)
+        f32x16_t s[CB];
+        int kb0 = 0;
+        for (; kb0 + CB < p.nkb; kb0 += CB) {
+            scores(kb0, qf, s);
+            absorb(kb0, s, o, mrun, lrun, std::false_type{});
         }
+        scores(kb0, qf, s);
+        absorb(kb0, s, o, mrun, lrun, std::true_type{});     // only the last chunk can hold keys >= N
+
+        __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the next block's Q (requested a whole block ago); see load_q
         const float ltot = lrun + __shfl_xor(lrun, 32, 64);
         const float inv = 1.0f / ltot;
         const int q = qb * 32 + l31;
@@ -235,25 +255,35 @@ int pgv_launch_vit_attn(pgv_ctx* ctx, int dtype, const void* qkv, int ld, void* 
     a.qkv = (const char*)qkv; a.out = (char*)out; a.ld = ld; a.ldo = ldo; a.N = N; a.C = C; a.heads = heads;
     a.nkb = (N + 31) / 32;
     const int npad = a.nkb * 32;
-    a.vt_stride = npad * 2 + 16;
     a.scale_log2e = 0.125f * 1.4426950408889634f;
     { static int abl = -1; if (abl < 0) { const char* e = getenv("PGV_ATTN_ABLATE"); abl = e ? atoi(e) : 0; } a.abl = abl; }
-    const size_t lds = (size_t)npad * 128 + (size_t)HD * a.vt_stride + 16;    // + the query-block counter
+    const size_t lds = (size_t)npad * 256 + 16;    // K + V images + the query-block counter
     PGV_CHECK(lds <= 160 * 1024, "vit_attn: %d tokens per frame need %zu B of LDS (> 160 KiB)", N, lds);
     const int nw = 4;
     pgv_prof_begin(ctx, 1, s);
+#define PGV_ATTN_LAUNCH(T_, ABL_) do { \
+        static bool cfg = false; \
+        if (!cfg) { PGV_HIP(hipFuncSetAttribute((const void*)vit_attn_kernel<T_, ABL_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); cfg = true; } \
+        hipLaunchKernelGGL((vit_attn_kernel<T_, ABL_>), dim3(T * heads), dim3(nw * 64), lds, s, a); } while (0)
     if (dtype == PGV_F16) {
-        static bool cfg = false;
-        if (!cfg) { PGV_HIP(hipFuncSetAttribute((const void*)vit_attn_kernel<TF16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); cfg = true; }
-        hipLaunchKernelGGL((vit_attn_kernel<TF16>), dim3(T * heads), dim3(nw * 64), lds, s, a);
+        PGV_ATTN_LAUNCH(TF16, 0);
     } else if (dtype == PGV_BF16) {
-        static bool cfg = false;
-        if (!cfg) { PGV_HIP(hipFuncSetAttribute((const void*)vit_attn_kernel<TBF16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); cfg = true; }
-        hipLaunchKernelGGL((vit_attn_kernel<TBF16>), dim3(T * heads), dim3(nw * 64), lds, s, a);
+        switch (a.abl & 0x78) {                      // fine-grained ablations exist for bf16 only
+            case 0: PGV_ATTN_LAUNCH(TBF16, 0); break;
+            case 8: PGV_ATTN_LAUNCH(TBF16, 8); break;
+            case 16: PGV_ATTN_LAUNCH(TBF16, 16); break;
+            case 32: PGV_ATTN_LAUNCH(TBF16, 32); break;
+            case 64: PGV_ATTN_LAUNCH(TBF16, 64); break;
+            case 48: PGV_ATTN_LAUNCH(TBF16, 48); break;
+            case 72: PGV_ATTN_LAUNCH(TBF16, 72); break;
+            case 120: PGV_ATTN_LAUNCH(TBF16, 120); break;
+            default: pgv_set_error("vit_attn: unsupported ablation %d", a.abl); return PGV_EINVAL;
+        }
     } else {
         pgv_set_error("vit_attn: unsupported dtype %d", dtype);
         return PGV_EINVAL;
     }
+#undef PGV_ATTN_LAUNCH
     PGV_HIP(hipGetLastError());
     pgv_prof_end(ctx, 1, s, 4.0 * (double)T * heads * (double)N * N * HD, 2.0 * 4.0 * (double)T * N * C);
     return PGV_OK;
