@@ -427,7 +427,7 @@ __global__ __launch_bounds__(512) void gemv_mfma_kernel(GemvArgs p) {
     if constexpr (MODE == GV_SWIGLU) {
         float v[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const float g = tot[0][r]; v[r] = g / (1.0f + __expf(-g)) * tot[1][r]; }
+        for (int r = 0; r < 4; ++r) { const float g = tot[0][r]; v[r] = g * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(g * -1.4426950408889634f)) * tot[1][r]; }   // same SiLU as gemm.hip
         *(u32x2_t*)(p.out + ((size_t)b * p.ldo + n0) * 2) = pack4<T>(v[0], v[1], v[2], v[3]);
     } else if constexpr (MODE == GV_STORE16) {
         *(u32x2_t*)(p.out + ((size_t)b * p.ldo + n0) * 2) = pack4<T>(tot[0][0], tot[0][1], tot[0][2], tot[0][3]);
