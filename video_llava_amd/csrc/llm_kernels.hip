@@ -113,7 +113,7 @@ struct PrefillAttnArgs {
 template <typename T>
 __global__ __launch_bounds__(256) void prefill_attn_kernel(PrefillAttnArgs p) {
     __shared__ __attribute__((aligned(16))) char Ks[64 * 256];
-    __shared__ __attribute__((aligned(16))) char Vt[128 * 144];
+    __shared__ __attribute__((aligned(16))) char Vs[64 * 256];   // row-major like K; 16-B chunk index ^ ((row & 3) << 2)
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.z, h = blockIdx.y;
@@ -141,6 +141,10 @@ __global__ __launch_bounds__(256) void prefill_attn_kernel(PrefillAttnArgs p) {
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) koffs[kk] = ((kk * 2 + hi) ^ (l31 & 15)) << 4;
 
+    // transposing V reads: lane i of 16-lane group g addresses key (4 hi + i/4) of a 16-key slice, d columns j*32 + g*16 + (i%4)*4 .. +3
+    const int li = lane & 15, lg = (lane >> 4) & 1;
+    const int voff0 = (4 * hi + (li >> 2)) * 256 + (((lg * 2 + ((li & 3) >> 1)) ^ ((li >> 2) << 2)) << 4) + (li & 1) * 8;   // d block j: ^ (j * 64)
+
     const int kend = min(S, q0 + 128);
     for (int kc0 = 0; kc0 < kend; kc0 += 64) {
         __syncthreads();
@@ -157,20 +161,20 @@ __global__ __launch_bounds__(256) void prefill_attn_kernel(PrefillAttnArgs p) {
                                                  (__attribute__((address_space(3))) void*)(Ks + g * 1024), 16, 0, 0);
             }
         }
-        // stage V^T
+        // stage V the same way (row-major; the V^T MFMA fragments come out of it through ds_read_b64_tr_b16, see vit_attn.hip).  The 32 lanes of
+        // an LDS cycle of those reads touch 4 consecutive keys x 64 B: chunk ^ ((row & 3) << 2) puts them in the four 64-B quarters of a bank row.
+        // (The first version transposed V through registers with ds_write_b16: SQ_LDS_BANK_CONFLICT was 84 % of SQ_LDS_IDX_ACTIVE.)
+        {
+            const int srow = lane >> 4, slot = lane & 15;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int idx = tid + it * 256;
-            const int key = idx >> 4, dc = idx & 15;
-            typename T::v8 v;
-            if (kc0 + key < S) v = *(const typename T::v8*)(vbase + ((size_t)(kc0 + key) * HD + dc * 8) * 2);
-            else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (typename T::elem)0.0f;
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int g = w * 4 + g4;
+                const int row = g * 4 + srow;
+                const int chunk = slot ^ ((row & 3) << 2);
+                const int vr = min(kc0 + row, S - 1);      // rows past S: finite duplicates, their probabilities are exactly 0
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + ((size_t)vr * HD + chunk * 8) * 2),
+                                                 (__attribute__((address_space(3))) void*)(Vs + g * 1024), 16, 0, 0);
             }
-            const int pos = (key & ~12) | ((key & 4) << 1) | ((key & 8) >> 1);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) *(typename T::elem*)(Vt + (dc * 8 + e) * 144 + pos * 2) = v[e];
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -225,11 +229,13 @@ __global__ __launch_bounds__(256) void prefill_attn_kernel(PrefillAttnArgs p) {
                 typename T::v8 pa;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) pa[e] = T::from_f32(s[c][ks * 8 + e]);
-                const int col = (c * 32 + ks * 16 + hi * 8) * 2;
+                const char* vb = Vs + (c * 32 + ks * 16) * 256;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const typename T::v8 vf = *(const typename T::v8*)(Vt + (j * 32 + l31) * 144 + col);
-                    o[j] = T::mfma32(vf, pa, o[j]);
+                    const char* a0 = vb + (voff0 ^ (j * 64));
+                    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)a0);
+                    const s16x4_t up = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(a0 + 8 * 256));
+                    o[j] = T::mfma32(__builtin_bit_cast(typename T::v8, __builtin_shufflevector(lo, up, 0, 1, 2, 3, 4, 5, 6, 7)), pa, o[j]);
                 }
             }
     }

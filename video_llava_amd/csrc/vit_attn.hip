@@ -25,7 +25,6 @@ namespace {
 
 constexpr int HD = 64;        // CLIP-L head_dim
 constexpr int CB = 3;         // key blocks (of 32) per online-softmax chunk
-typedef short s16x4_t __attribute__((ext_vector_type(4)));
 
 struct AttnArgs {
     const char* qkv;   // [T*N, ld] 16-bit: q at col 0, k at col C, v at col 2C (fused qkv GEMM output)
