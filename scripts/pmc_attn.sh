@@ -20,3 +20,4 @@ except Exception as e:
     print("pmc read failed:", e)
 PY
 done
+rm -rf gpurun_out/pmc_attn/p*/

@@ -11,3 +11,4 @@ for grp in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL SQ_LDS
 done
 python scripts/pmc_sq_summary.py gpurun_out/pmc_sq/p*/pmc_results.db > gpurun_out/pmc_sq/summary.txt 2>&1
 cat gpurun_out/pmc_sq/summary.txt
+rm -rf gpurun_out/pmc_sq/p*/

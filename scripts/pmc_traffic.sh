@@ -10,3 +10,4 @@ timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/pmc/fetch -o
 timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/pmc/write -o pmc -- python bench.py $ARGS > gpurun_out/pmc/write.json 2> gpurun_out/pmc/write.err
 ls -la gpurun_out/pmc/fetch gpurun_out/pmc/write
 python scripts/pmc_summary.py gpurun_out/pmc/fetch/pmc_results.db gpurun_out/pmc/write/pmc_results.db gpurun_out/pmc/pmc_traffic.json | head -30
+rm -rf gpurun_out/pmc/fetch gpurun_out/pmc/write
