@@ -116,6 +116,32 @@ def test_gemm_rejects_bad_shapes(ctx):
 # --------------------------------------------------------------------------------------------------
 # norms
 # --------------------------------------------------------------------------------------------------
+# --------------------------------------------------------------------------------------------------
+# ViT attention building block (CLIPAttention eager math, HF:clip/modeling_clip.py:259-277) through the C ABI
+# --------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 1e-3), (torch.bfloat16, 8e-3)])
+@pytest.mark.parametrize("T,N,heads", [(3, 1, 2), (2, 5, 16), (2, 31, 2), (2, 32, 2), (3, 33, 2), (2, 96, 4), (2, 97, 4), (5, 257, 16), (2, 577, 16)])
+def test_vit_attention_block(ctx, dtype, tol, T, N, heads):
+    """Token counts around every boundary of the kernel: a single key, one partial 32-key block, exact block / chunk multiples (32, 96) and
+    one past them (33, 97: the single-valid-key block both CLIP sizes end with), 257 (224 px) and 577 (336 px).  Random q/k/v with distinct
+    rows make the check sensitive to any transposition or key-order slip in the LDS images."""
+    from video_llava_amd import _lib
+    C = heads * 64
+    g = torch.Generator().manual_seed(1000 * N + T)
+    qkv = (torch.randn(T * N, 3 * C, generator=g) * 1.5).to(dtype)
+    out = torch.full((T * N, C), float("nan"), dtype=dtype, device=DEV)
+    qd = qkv.to(DEV)
+    _lib.check(ctx.lib.pgv_vit_attention(ctx.handle, _lib.dtype_code(dtype), qd.data_ptr(), out.data_ptr(), T, N, C, heads, _lib.stream_ptr()), "pgv_vit_attention")
+    torch.cuda.synchronize()
+    x = qkv.float().view(T, N, 3, heads, 64)
+    q, k, v = (x[:, :, i].permute(0, 2, 1, 3) for i in range(3))            # [T, heads, N, 64]
+    ref = torch.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1) @ v
+    ref = ref.permute(0, 2, 1, 3).reshape(T * N, C)
+    assert torch.isfinite(out.float()).all()
+    e = rel(out, ref)
+    assert e <= tol, f"N={N}: rel err {e:.3e}"
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("cols", [512, 1024, 4096, 5120])
 def test_layernorm_rmsnorm(ctx, dtype, cols):
