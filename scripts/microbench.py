@@ -54,7 +54,7 @@ def bench_gemm_ablate(ctx, dtype=torch.bfloat16):
     """gemm_w4 with PGV_GEMM_ABLATE set by the caller (bit0 no DMA, bit1 no ds_reads, bit2 no MFMA, bit3 no counted wait, bit4 no barrier;
     plain BIAS epilogue only): timing ablations, results are garbage."""
     print("== gemm ablation (ABLATE=%s) ==" % os.environ.get("PGV_GEMM_ABLATE", "0"))
-    for (m, n, k, name) in ((102800, 3072, 1024, "vit qkv"), (8192, 8192, 8192, "8192^3"), (16384, 4096, 16384, "long K")):
+    for (m, n, k, name) in ((205600, 3072, 1024, "vit qkv"), (205600, 1024, 4096, "fc2 shape"), (8192, 8192, 8192, "8192^3"), (16384, 4096, 16384, "long K")):
         a = torch.randn(m, k, device=DEV).to(dtype)
         w = (torch.randn(n, k, device=DEV) * 0.02).to(dtype)
         bias = torch.randn(n, device=DEV)

@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4(KArgs p) {
         tile_coords_v(vb, total, p.ntm, p.ntn, tm, tn);
         asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");             // last MFMA result -> first accumulator read
         // staging = the slot of the W tile just consumed: free until the next K-step's G0 refills it
-        epilogue_w4<T, EPI>(p, acc, smem + stg_slot * SLOT + w * 8192, tm * BM + wr * 128, tn * BN + wc * 128, lane);
+        if constexpr (!(ABL & 32)) epilogue_w4<T, EPI>(p, acc, smem + stg_slot * SLOT + w * 8192, tm * BM + wr * 128, tn * BN + wc * 128, lane);
         __builtin_amdgcn_s_barrier();                                 // the next G0 refills the staging slot: every wave must be done with it
     }
 #undef PGV_W4_KSTEP
@@ -357,7 +357,7 @@ int launch_w4(const KArgs& k, hipStream_t s, int num_cu) {
     static int abl = -1;
     if (abl < 0) { const char* e = getenv("PGV_GEMM_ABLATE"); abl = e ? atoi(e) : 0; }
     // Timing ablations (results are garbage), plain BIAS epilogue in bf16 only -- PGV_GEMM_ABLATE bits: 1 no DMA, 2 no fragment reads,
-    // 4 no MFMA, 8 no counted vmcnt wait, 16 no barrier (scripts/microbench.py ablate; the table in DESIGN.md 3.1)
+    // 4 no MFMA, 8 no counted vmcnt wait, 16 no barrier, 32 no epilogue (scripts/microbench.py ablate; the table in DESIGN.md 3.1)
     if constexpr (EPI == PGV_EPI_BIAS && T::id == PGV_BF16) {
         switch (abl) {
             case 1: return launch_w4_inst<T, EPI, 1>(k, s, num_cu);
@@ -365,6 +365,7 @@ int launch_w4(const KArgs& k, hipStream_t s, int num_cu) {
             case 6: return launch_w4_inst<T, EPI, 6>(k, s, num_cu);
             case 14: return launch_w4_inst<T, EPI, 14>(k, s, num_cu);
             case 24: return launch_w4_inst<T, EPI, 24>(k, s, num_cu);
+            case 32: return launch_w4_inst<T, EPI, 32>(k, s, num_cu);
             default: break;
         }
     }
