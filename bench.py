@@ -48,6 +48,10 @@ def parse():
     ap.add_argument("--workload", choices=["full", "vision"], default="full",
                     help="full = BASELINE config 3/4 (frames -> answer); vision = config 2 (ViT + pool + projector)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap-vision", action="store_true",
+                    help="EXPERIMENT: additionally time the same K steps with step i+1's vision stage on a second stream (own workspace) beside step i's "
+                         "decode; reported as overlap_vision, never as `value`")
+    ap.add_argument("--vision-cu-mask", default="", help="with --overlap-vision: CU mask of the vision stream, '<first|stride>:<n>' (first n CUs / every 256/n-th CU)")
     ap.add_argument("--host-frames", action="store_true",
                     help="additionally time the same steps with the uint8 frames uploaded from pinned host memory inside the timed region "
                          "(reported as pcie_inclusive; `value` always has the frames resident in HBM)")
@@ -238,6 +242,64 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = n_global * args.steps / elapsed
     vit_ms = sum(a.elapsed_time(b) for a, b in vit_events) / max(len(vit_events), 1)      # frames -> pooled features, per step
+    overlap = None
+    if args.overlap_vision and args.workload == "full":
+        # Same K batches, every kernel still runs: the vision stage of batch i+1 is enqueued on a second stream (second pgv context = own
+        # workspace) before batch i's prefill + decode are enqueued on the main stream.  Decode is HBM-bound, the ViT is MFMA/power-bound.
+        ctx_v = _lib.Context(dev.index)
+        # decode runs on a pool stream too: the legacy default stream would synchronise with the (blocking) CU-masked stream
+        s_main = torch.cuda.Stream(dev)
+        s_main.wait_stream(torch.cuda.current_stream(dev))
+        if args.vision_cu_mask:
+            import ctypes
+            kind, n = args.vision_cu_mask.split(":"); n = int(n)
+            bits = list(range(n)) if kind == "first" else list(range(0, 256, 256 // n))
+            words = (ctypes.c_uint32 * 8)(*[sum(1 << (b % 32) for b in bits if b // 32 == wd) for wd in range(8)])
+            hip = ctypes.CDLL("libamdhip64.so")
+            raw = ctypes.c_void_p()
+            rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(raw), 8, words)
+            if rc != 0:
+                raise SystemExit(f"hipExtStreamCreateWithCUMask failed: {rc}")
+            s_vis = torch.cuda.ExternalStream(raw.value, device=dev)
+        else:
+            s_vis = torch.cuda.Stream(dev)
+
+        def vision_async():
+            s_vis.wait_stream(s_main)
+            tower.ctx = ctx_v
+            with torch.cuda.stream(s_vis):
+                pooled = vision(frames)
+                ev = torch.cuda.Event(); ev.record(s_vis)
+            tower.ctx = ctx
+            return pooled, ev
+
+        def run_overlapped(k):
+            nxt = vision_async()
+            for i in range(k):
+                pooled, ev = nxt
+                s_main.wait_event(ev)
+                pooled.record_stream(s_main)
+                nxt = vision_async() if i + 1 < k else None
+                with torch.cuda.stream(s_main):
+                    out = model.generate(prompts, video_spatio_temporal_features=pooled, do_sample=False, max_new_tokens=NEW, eos_token_id=None, chunk=64)
+                    toks = torch.stack([out[b, len(prompts[b]):len(prompts[b]) + NEW] for b in range(B)]).to(torch.int32)
+                    parallel.gather_answers(toks, torch.full((B,), NEW, dtype=torch.int32, device=dev), n_global, rank, world)
+
+        run_overlapped(1)
+        barrier()
+        tv = time.perf_counter()
+        vision_async(); barrier()
+        vis_alone_ms = (time.perf_counter() - tv) * 1e3
+        t1 = time.perf_counter()
+        run_overlapped(args.steps)
+        barrier()
+        el = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            el = float(tt[0])
+        overlap = {"value": n_global * args.steps / el, "unit": "videos/sec", "ms_per_step": el / args.steps * 1e3,
+                   "vision_alone_on_its_stream_ms": vis_alone_ms, "vision_cu_mask": args.vision_cu_mask or None}
     pcie = None
     if args.host_frames:                              # same steps, frames handed over as host buffers (the reference's boundary: PIL images on the host)
         host = frames.cpu().pin_memory()
@@ -317,6 +379,8 @@ def main():
         }
         if pcie:
             line["pcie_inclusive"] = pcie
+        if overlap:
+            line["overlap_vision"] = overlap
         if fam:
             line["families"] = fam
         if roofline:
