@@ -317,6 +317,11 @@ def main():
         pcie = {"value": n_global * args.steps / el, "unit": "videos/sec", "ms_per_step": el / args.steps * 1e3,
                 "h2d_bytes_per_step_per_gpu": int(host.numel())}
     clip_feat_tflops = B * T * VIT_FLOP_PER_FRAME_23L[S] / (vit_ms * 1e-3) / 1e12
+    clip_feat_tflops_total = clip_feat_tflops                 # sum over ranks of each rank's own stage rate
+    if world > 1:
+        tt = torch.tensor([clip_feat_tflops], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.SUM)
+        clip_feat_tflops_total = float(tt[0])
 
     # ---- profiled pass: hipEvent pairs around every launch of each kernel family, on the launch stream -----------------
     fam = {}
@@ -375,6 +380,7 @@ def main():
                        "parallelism": f"dp{world}"},
             # CLIP-feature stage (preprocess + ViT 23 layers + pool), algorithmic 155.29 GFLOP/frame, per GPU
             "clip_feat_tflops": clip_feat_tflops, "clip_feat_frac_of_mfma_peak": clip_feat_tflops / PEAK_MFMA_TFLOPS,
+            "clip_feat_tflops_all_gpus": clip_feat_tflops_total,
             "clip_feat_ms_per_step": vit_ms,
         }
         if pcie:
