@@ -133,6 +133,52 @@ def test_qa_runner_end_to_end_matches_oracle(ctx, tmp_path):
         assert got[:k] == ref[:k], (n, got, ref, margins)
 
 
+def test_consistency_runner_end_to_end_matches_oracle(ctx, tmp_path):
+    """run_inference_benchmark_consistency: Q1 and Q2 on the same clip (features computed once per pair), schema {.., pred1, pred2}, a sample
+    whose clip is missing is dropped; predictions checked against the oracle's greedy tokens."""
+    from video_llava_amd.eval import run_inference_benchmark_consistency as cons
+    from video_llava_amd.inference import build_prompt
+    from video_llava_amd.model.video_chatgpt import VideoChatGPTConfig, VideoChatGPTLlamaForCausalLM, VisionConfig
+    ccfg, lcfg = synth.CLIP_TINY, synth.LLAMA_TINY
+    cw = synth.make_clip_weights(ccfg, seed=41)
+    lw = synth.make_llama_weights(lcfg, seed=42, head_std=0.08)
+    tower = _tower(ccfg, cw)
+    model = VideoChatGPTLlamaForCausalLM(VideoChatGPTConfig(vocab_size=lcfg.vocab, hidden_size=lcfg.hidden, intermediate_size=lcfg.inter,
+                                                            num_hidden_layers=lcfg.layers, num_attention_heads=lcfg.heads, eos_token_id=None,
+                                                            max_position_embeddings=2048),
+                                         VisionConfig(frame_size=ccfg.image), torch.float16)
+    model.load_state_dict(lw)
+    vc = model.get_model().vision_config
+    vc.vid_patch_token, vc.vid_start_token, vc.vid_end_token, vc.use_vid_start_end = lcfg.vocab - 3, lcfg.vocab - 2, lcfg.vocab - 1, True
+    tok = _Tok(lcfg.vocab)
+
+    class IP:
+        crop_size = {"height": ccfg.image, "width": ccfg.image}
+    V = 100 + (ccfg.image // ccfg.patch) ** 2
+    vd = tmp_path / "v"; vd.mkdir()
+    for i, n in enumerate(["c1", "c2"]):
+        np.save(vd / f"{n}.npy", synth.make_frames(6 + i, ccfg.image, seed=50 + i))
+    gt = [{"video_name": "c1", "Q1": "what is shown?", "Q2": "describe the clip", "A": "x"},
+          {"video_name": "nope", "Q1": "a?", "Q2": "b?", "A": "y"},
+          {"video_name": "c2", "Q1": "who is there?", "Q2": "who appears?", "A": "z"}]
+    (tmp_path / "gt.json").write_text(json.dumps(gt))
+    NEW = 5
+    args = cons.parse_args(["--video_dir", str(vd), "--gt_file", str(tmp_path / "gt.json"), "--output_dir", str(tmp_path / "out"), "--output_name", "c",
+                            "--model-name", "x", "--projection_path", "y", "--batch", "3", "--max_new_tokens", str(NEW)])
+    out = cons.run_inference(args, components=(model, tower, tok, IP(), V))
+    assert json.load(open(tmp_path / "out" / "c.json")) == out and [o["video_name"] for o in out] == ["c1", "c2"]
+    for o in out:
+        frames = np.load(vd / f"{o['video_name']}.npy")
+        pooled = ovis.spatio_temporal_pool_torch(ovis.clip_select_features(ovis.clip_preprocess(frames), cw, ccfg))
+        for qk, pk in (("Q1", "pred1"), ("Q2", "pred2")):
+            prompt, _ = build_prompt(o[qk], "pg-video-llava", V, True)
+            ref, margins = ollm.greedy_generate(lw, lcfg, tok([prompt]).input_ids[0], pooled.float(), lcfg.vocab - 2, lcfg.vocab - 1, lcfg.vocab - 3, NEW,
+                                                return_margins=True)
+            got = [int(t) for t in o[pk].split()]
+            k = next((i for i, m in enumerate(margins) if m < 0.02), NEW)
+            assert got[:k] == ref[:k], (o["video_name"], qk, got, ref, margins)
+
+
 def test_chat_interface_multi_turn_matches_oracle(ctx, tmp_path):
     """VideoChatGPTInterface (reference chat.py): two turns on one clip.  The vision stage runs once per uploaded clip; every turn's
     prompt is the reference's (first turn re-rooted on the conv_mode template, <video> replaced by the placeholder run once) and the

@@ -267,3 +267,64 @@ def test_qa_runner_host_logic(tmp_path):
     assert samples[1] == {"video_name": "zz", "question": "why?", "id": "zz_0", "answer": "no"}
     out = qa.build_output(samples, ["a dog", None])
     assert out == [{"id": "x1_0", "question": "what?", "answer": "yes", "pred": "a dog"}]
+
+
+def test_sibling_runners_host_logic(tmp_path, monkeypatch):
+    """Dataset adapters of the other eval runners (file naming, sample / output schema, drop-on-failure policy) with the sharded
+    answering core stubbed out: reference video_chatgpt/eval/run_inference_{benchmark_general,benchmark_consistency,qa_msrvtt,qa_msvd,qa_tgif}.py."""
+    from PIL import Image
+    from video_llava_amd.eval import _sharded
+    from video_llava_amd.eval import run_inference_benchmark_consistency as cons
+    from video_llava_amd.eval import run_inference_benchmark_general as gen
+    from video_llava_amd.eval import run_inference_qa_msrvtt as msrvtt
+    from video_llava_amd.eval import run_inference_qa_msvd as msvd
+    from video_llava_amd.eval import run_inference_qa_tgif as tgif
+
+    class _IP:
+        crop_size = {"height": 224, "width": 224}
+    seen = {}
+
+    def fake_setup(args, components=None):
+        return 0, 1, (None, None, None, _IP(), 356)
+
+    def fake_answer(args, tasks, components, load_frames, rank, world):
+        seen["tasks"] = tasks
+        return [None if t["path"] is None else f"ans:{t['question']}" for t in tasks]
+    monkeypatch.setattr(_sharded, "setup", fake_setup)
+    monkeypatch.setattr(_sharded, "answer_tasks", fake_answer)
+    vd = tmp_path / "v"; vd.mkdir()
+    out = tmp_path / "o"
+    common = ["--video_dir", str(vd), "--output_dir", str(out), "--output_name", "r", "--model-name", "m", "--projection_path", "p"]
+
+    # general + consistency: {video_name}.{mp4,avi,mov,mkv}; a sample with any failed question is dropped
+    (vd / "a.avi").write_bytes(b""); (vd / "a.mkv").write_bytes(b"")
+    gt = [{"video_name": "a", "Q": "q?", "A": "x", "Q1": "q1?", "Q2": "q2?"}, {"video_name": "missing", "Q": "z?", "A": "y", "Q1": "m1", "Q2": "m2"}]
+    (tmp_path / "gt.json").write_text(json.dumps(gt))
+    r = gen.run_inference(gen.parse_args(common + ["--gt_file", str(tmp_path / "gt.json")]))
+    assert seen["tasks"][0]["path"].endswith("a.avi") and seen["tasks"][1]["path"] is None
+    assert r == [dict(gt[0], pred="ans:q?")] and json.load(open(out / "r.json")) == r
+    r = cons.run_inference(cons.parse_args(common + ["--gt_file", str(tmp_path / "gt.json")]))
+    assert [t["question"] for t in seen["tasks"]] == ["q1?", "q2?", "m1", "m2"]
+    assert r == [dict(gt[0], pred1="ans:q1?", pred2="ans:q2?")]
+
+    # MSRVTT: video{video_id}.mp4; MSVD: mapper lines "<name> vid<id>" and .avi
+    (vd / "video7.mp4").write_bytes(b""); (vd / "clipA.avi").write_bytes(b"")
+    gt2 = [{"video_id": 7, "question": "who?", "answer": "man", "id": 1}, {"video_id": 8, "question": "what?", "answer": "dog", "id": 2}]
+    (tmp_path / "gt2.json").write_text(json.dumps(gt2))
+    r = msrvtt.run_inference(msrvtt.parse_args(common + ["--gt_file", str(tmp_path / "gt2.json")]))
+    assert seen["tasks"][0]["path"].endswith("video7.mp4") and r == [dict(gt2[0], pred="ans:who?")]
+    (tmp_path / "map.txt").write_text("clipA vid7\nclipB vid8\n")
+    a = msvd.parse_args(common + ["--gt_file", str(tmp_path / "gt2.json"), "--mapper", str(tmp_path / "map.txt")])
+    assert msvd.load_mapper(a.mapper) == {7: "clipA", 8: "clipB"}
+    r = msvd.eval_model(a)
+    assert seen["tasks"][0]["path"].endswith("clipA.avi") and seen["tasks"][1]["path"] is None and r == [dict(gt2[0], pred="ans:who?")]
+
+    # TGIF: tab-separated rows, {gif_name}.gif, 8 segment-centred frames at native size
+    assert tgif.gif_frame_indices(40) == [2, 7, 12, 17, 22, 26, 31, 36] and tgif.gif_frame_indices(3) == [0, 0, 0, 1, 1, 1, 2, 2]
+    frames = [Image.fromarray(np.full((20, 30, 3), 10 * i, dtype=np.uint8)) for i in range(12)]
+    frames[0].save(vd / "g1.gif", save_all=True, append_images=frames[1:], duration=50, loop=0)
+    imgs = tgif.load_video_from_gif(str(vd / "g1.gif"))
+    assert len(imgs) == 8 and imgs[0].size == (30, 20) and imgs[0].mode == "RGB"
+    (tmp_path / "t.tsv").write_text("gif_name\tquestion\tdescription\tanswer\ng1\thow many?\ta cat\t2\ng9\twhere?\ta dog\tpark\n")
+    r = tgif.run_inference(tgif.parse_args(common + ["--gt_file", str(tmp_path / "t.tsv")]))
+    assert r == [{"gif_name": "g1", "question": "how many?", "description": "a cat", "answer": "2", "pred": "ans:how many?"}]

@@ -1,0 +1,129 @@
+"""Shared core of the eval runners: answer a list of (video, question) tasks data-parallel over the ranks of a
+`torch.distributed.run` launch and hand every rank the same list of prediction strings.
+
+The reference's runners (video_chatgpt/eval/run_inference_*.py) all share one loop -- load the video, call
+`video_chatgpt_infer`, append the sample with its prediction, print and skip on any exception -- and differ only in how a
+sample names its video file and which keys the output record carries.  Here that loop is one function: tasks are sharded over
+the ranks (one process per GPU), each rank answers its shard in batches (one ViT pass per clip, batched prefill + KV-cached
+greedy decode in libpgv) and the only collective is the final all-gather of the answer token ids (video_llava_amd/parallel.py).
+A task whose video is missing or fails yields None (the reference prints and leaves the sample out).
+`do_sample=True` restores the reference's temperature-0.2 sampling through `video_chatgpt_infer`, one task at a time.
+"""
+from __future__ import annotations
+
+import torch
+
+
+def add_runtime_arguments(parser):
+    """Flags this package adds to every runner on top of the reference's."""
+    parser.add_argument("--batch", type=int, default=8, help="clips answered together per GPU (greedy decoding)")
+    parser.add_argument("--max_new_tokens", type=int, default=1024)
+    parser.add_argument("--do_sample", action="store_true", help="reference decoding: temperature-0.2 sampling, one clip at a time")
+    return parser
+
+
+def setup(args, components=None):
+    """-> (rank, world, components).  components = (model, vision_tower, tokenizer, image_processor, video_token_len) may be injected."""
+    from .. import parallel
+    rank, world, local = parallel.init_distributed()
+    if components is None:
+        from .model_utils import initialize_model
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local)
+        components = initialize_model(args.model_name, args.projection_path)
+    if getattr(args, "use_asr", False):
+        raise NotImplementedError("--use_asr needs the WhisperX transcript stack, which is outside this package's hot path")
+    return rank, world, components
+
+
+def answer_tasks(args, tasks, components, load_frames, rank, world):
+    """tasks: [{"path": str | None, "name": str, "question": str}] -> [str | None] in task order, identical on every rank."""
+    from .. import parallel
+    from ..inference import build_prompt, video_chatgpt_infer, video_features
+
+    model, vision_tower, tokenizer, image_processor, video_token_len = components
+    use_se = model.get_model().vision_config.use_vid_start_end
+    stop_strs = {}
+
+    def infer_batch(indices):
+        """-> (tokens [n, <= max_new] int32, lengths); a task that cannot be loaded gets length 0."""
+        prompts, feats, keep = [], [], []
+        last_path, last_feat = None, None
+        for j, idx in enumerate(indices):
+            t = tasks[idx]
+            if t["path"] is None:
+                print(f"Error processing video file '{t['name']}': not found")
+                continue
+            try:
+                if t["path"] != last_path:                             # consecutive questions on one clip share its features
+                    last_feat = video_features(load_frames(t["path"]), vision_tower, image_processor)
+                    last_path = t["path"]
+                feats.append(last_feat)
+                prompt, stop = build_prompt(t["question"], args.conv_mode, video_token_len, use_se)
+                stop_strs[idx] = stop
+                prompts.append(tokenizer([prompt]).input_ids[0])
+                keep.append(j)
+            except Exception as e:                                     # noqa: BLE001 -- the reference's print-and-continue
+                print(f"Error processing video file '{t['name']}': {e}")
+        toks = torch.zeros(len(indices), args.max_new_tokens, dtype=torch.int32)
+        lens = [0] * len(indices)
+        if keep:
+            out = model.generate(prompts, video_spatio_temporal_features=torch.stack(feats), do_sample=False,
+                                 max_new_tokens=args.max_new_tokens).cpu()
+            eos = model.config.eos_token_id
+            for r, j in enumerate(keep):
+                new = out[r, len(prompts[r]):].tolist()
+                if eos is not None and eos in new:
+                    new = new[:new.index(eos)]
+                new = new[:args.max_new_tokens]
+                toks[j, :len(new)] = torch.tensor(new, dtype=torch.int32)
+                lens[j] = max(len(new), 1) if new else 0
+        return toks, lens
+
+    if args.do_sample:
+        preds = [None] * len(tasks)
+        for idx in parallel.shard_indices(len(tasks), rank, world):
+            t = tasks[idx]
+            try:
+                if t["path"] is None:
+                    raise FileNotFoundError(t["name"])
+                preds[idx] = video_chatgpt_infer(load_frames(t["path"]), t["question"], args.conv_mode, model, vision_tower, tokenizer,
+                                                 image_processor, video_token_len, None, max_new_tokens=args.max_new_tokens)
+            except Exception as e:                                     # noqa: BLE001
+                print(f"Error processing video file '{t['name']}': {e}")
+        if world > 1:
+            gathered = [None] * world
+            torch.distributed.all_gather_object(gathered, preds)
+            preds = [next((g[i] for g in gathered if g[i] is not None), None) for i in range(len(tasks))]
+        return preds
+
+    device = vision_tower.device if hasattr(vision_tower, "device") else torch.device("cpu")
+    answers = parallel.run_sharded(len(tasks), infer_batch, args.max_new_tokens, rank, world, device, per_gpu_batch=args.batch)
+    preds = []
+    for idx, ids in enumerate(answers):
+        if not ids:
+            preds.append(None)
+            continue
+        text = tokenizer.batch_decode([ids], skip_special_tokens=True)[0].strip()
+        stop = stop_strs.get(idx) or build_prompt("", args.conv_mode, 1, use_se)[1]
+        preds.append(text.rstrip(stop).strip() if stop else text)     # the reference's own stop handling (inference.py:123)
+    return preds
+
+
+def first_existing(video_dir, stem, formats):
+    """First existing `{stem}{ext}` in the given extension order; None when absent."""
+    import os
+    for fmt in formats:
+        path = os.path.join(video_dir, f"{stem}{fmt}")
+        if os.path.exists(path):
+            return path
+    return None
+
+
+def write_output(args, output_list, rank):
+    import json
+    import os
+    if rank == 0:
+        with open(os.path.join(args.output_dir, f"{args.output_name}.json"), "w") as f:
+            json.dump(output_list, f)
+    return output_list
