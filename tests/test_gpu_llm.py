@@ -114,13 +114,15 @@ def test_ragged_batch_matches_single(ctx, golden_dir):
             assert singles[i] == ref
 
 
+@pytest.mark.parametrize("shape", ["7b", "13b"])
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 3e-3), (torch.bfloat16, 2.4e-2)])
-def test_7b_shaped_two_layers_vs_oracle(ctx, dtype, tol):
-    """BASELINE config 3 shapes (H 4096, I 11008, 32 heads, vocab 32003, 356 video rows, ~450-token prompt) on 2 layers.
+def test_7b_shaped_two_layers_vs_oracle(ctx, dtype, tol, shape):
+    """BASELINE config 3 shapes (H 4096, I 11008, 32 heads, vocab 32003, 356 video rows, ~450-token prompt) and config 5's 13B shapes
+    (H 5120, I 13824, 40 heads: ragged K-splits in every decode GEMV) on 2 layers.
     The decoder's parity bar is token-exact greedy decode.  Logits are additionally bounded at 3e-3 normwise (fp16):
     at width 4096 every 16-bit intermediate (normed x, q/k/v, probabilities, attention out, SwiGLU act, projected
     video rows) contributes ~2.8e-4 rms, ~16 of them over two layers -> ~1.5e-3 measured; the residual stream itself is fp32."""
-    cfg = synth.LlamaCfg(layers=2)
+    cfg = synth.LlamaCfg(layers=2) if shape == "7b" else synth.LlamaCfg(layers=2, hidden=5120, inter=13824, heads=40)
     # checkpoints are 16-bit: both the oracle and the HIP path get the same 16-bit-valued weights
     w = synth.quantize_weights(synth.make_llama_weights(cfg, seed=7, head_std=0.05), str(dtype).split(".")[1])
     m = _model(cfg, w, dtype)
@@ -134,7 +136,7 @@ def test_7b_shaped_two_layers_vs_oracle(ctx, dtype, tol):
     lg_ref = orc.prefill(ids, feats, START, END, PATCH)
     kv, nxt, lg = m.prefill([ids], feats.to(dtype), 512, want_logits=True)
     e = rel(lg[0], lg_ref[0])
-    print(f"7B-shaped 2-layer prefill logits rel err ({dtype}): {e:.3e}")
+    print(f"{shape}-shaped 2-layer prefill logits rel err ({dtype}): {e:.3e}")
     assert e < tol
     toks_ref, margins = ollm.greedy_generate(w, cfg, ids, feats, START, END, PATCH, n, return_margins=True)
     toks = [int(nxt[0])] + m.decode_greedy(kv, nxt, n - 1)[0].tolist()
