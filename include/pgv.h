@@ -49,8 +49,9 @@ size_t pgv_ctx_workspace_bytes(const pgv_ctx *ctx);
 
 /* Per-kernel-family device timers (hipEvent pairs around every launch of the family on the
  * caller's stream).  family: 0 = MFMA GEMM, 1 = ViT attention, 2 = LLM prefill attention,
- * 3 = decode GEMV, 4 = decode attention, 5 = everything else.  Off by default. */
-#define PGV_NFAMILY 6
+ * 3 = decode GEMV, 4 = decode attention, 5 = pooling, 6 = the short decode kernels (residual+RMSNorm, embedding, argmax).
+ * Off by default. */
+#define PGV_NFAMILY 7
 int pgv_prof_enable(pgv_ctx *ctx, int on);
 int pgv_prof_reset(pgv_ctx *ctx);
 /* synchronises the recorded events; fills launches / total ms / algorithmic flops / algorithmic bytes */

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libpgv.so")
 PGV_OK, PGV_EINVAL, PGV_EHIP, PGV_ENOMEM, PGV_ESTATE, PGV_ENAME = 0, 1, 2, 3, 4, 5
 PGV_F16, PGV_BF16, PGV_F32 = 0, 1, 2
 EPI_NONE, EPI_BIAS, EPI_BIAS_QGELU, EPI_BIAS_GELU, EPI_RESID, EPI_BIAS_RESID, EPI_SWIGLU, EPI_F32 = range(8)
-FAMILIES = ("gemm", "vit_attn", "llm_prefill_attn", "decode_gemv", "decode_attn", "other")
+FAMILIES = ("gemm", "vit_attn", "llm_prefill_attn", "decode_gemv", "decode_attn", "other", "decode_small")
 
 
 class VitConfig(C.Structure):

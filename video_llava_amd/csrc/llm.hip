@@ -307,9 +307,13 @@ extern "C" int pgv_kv_len(const pgv_kv* kv, int b) { return (kv && b >= 0 && b <
 // ---------------------------------------------------------------------------------------------
 static int lm_head_and_pick(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int B, int eos, int flags, hipStream_t s, int nparts = 0) {
     const int H = m->cfg.hidden, V = m->cfg.vocab;
+    pgv_prof_begin(ctx, 6, s);
     PGV_TRY(pgv_launch_rms_resid(m->dtype, kv->resid, kv->part, nparts, B, m->norm_g, m->cfg.eps, kv->xn, H, s));
+    pgv_prof_end(ctx, 6, s, 0.0, 0.0);
     PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_F32, m->fp8 ? m->q_head : m->lm_head, kv->xn, H, kv->logits, V, V, H, B, s, 1, m->fp8 ? m->s_head : nullptr));
+    pgv_prof_begin(ctx, 6, s);
     PGV_TRY(pgv_launch_argmax(kv->logits, V, B, kv->d_cur, kv->d_pos, kv->d_step, kv->d_hist, kv->max_seq, kv->d_done, eos, flags, s));
+    pgv_prof_end(ctx, 6, s, 0.0, 0.0);
     return PGV_OK;
 }
 
@@ -401,18 +405,24 @@ extern "C" int pgv_llm_prefill(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, const int32
 // ---------------------------------------------------------------------------------------------
 static int decode_enqueue(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int eos, int flags, hipStream_t s) {
     const int H = m->cfg.hidden, I = m->cfg.inter, heads = m->cfg.heads, B = kv->active;
+    pgv_prof_begin(ctx, 6, s);
     PGV_TRY(pgv_launch_embed_tok(m->dtype, kv->d_cur, m->embed, kv->resid, B, H, s));
+    pgv_prof_end(ctx, 6, s, 0.0, 0.0);
     double kv_bytes = 0;
     for (int b = 0; b < B; ++b) kv_bytes += 2.0 * 2.0 * (double)(kv->h_len[b] + 1) * H;
     for (int li = 0; li < m->cfg.layers; ++li) {
         const LlmLayer& l = m->layers[li];
         // input norm; for li > 0 it also folds the previous layer's down_proj split-K partials into the residual
+        pgv_prof_begin(ctx, 6, s);
         PGV_TRY(pgv_launch_rms_resid(m->dtype, kv->resid, kv->part, li == 0 ? 0 : kSplits, B, l.in_g, m->cfg.eps, kv->xn, H, s));
+        pgv_prof_end(ctx, 6, s, 0.0, 0.0);
         const bool q8 = m->fp8;
         PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_STORE16, q8 ? l.q_wqkv : l.wqkv, kv->xn, H, kv->qkv, 3 * H, 3 * H, H, B, s, 1, q8 ? l.s_wqkv : nullptr));
         PGV_TRY(pgv_launch_decode_attn(ctx, m->dtype, kv->qkv, kv->d_pos, m->rope, kv->Kc[li], kv->Vc[li], kv->ao, B, H, heads, kv->max_seq, kv_bytes, s));
         PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_PART, q8 ? l.q_wo : l.wo, kv->ao, H, kv->part, H, H, H, B, s, kSplits, q8 ? l.s_wo : nullptr));
+        pgv_prof_begin(ctx, 6, s);
         PGV_TRY(pgv_launch_rms_resid(m->dtype, kv->resid, kv->part, kSplits, B, l.post_g, m->cfg.eps, kv->xn, H, s));
+        pgv_prof_end(ctx, 6, s, 0.0, 0.0);
         PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_SWIGLU, q8 ? l.q_wgu : l.wgu, kv->xn, H, kv->act, I, 2 * I, H, B, s, 1, q8 ? l.s_wgu : nullptr));
         PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_PART, q8 ? l.q_wdown : l.wdown, kv->act, I, kv->part, H, H, I, B, s, kSplits, q8 ? l.s_wdown : nullptr));
     }
