@@ -252,6 +252,26 @@ def test_vit_l14_config1_vs_oracle(ctx, golden_dir, dtype, tol):
     assert rel(feat2, ref) < tol
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 1e-3), (torch.bfloat16, 8e-3)])
+def test_vit_l14_336_vs_oracle(ctx, dtype, tol):
+    """The tower the released PG-Video-LLaVA weights use: ViT-L/14@336, N = 577 tokens per frame, 3 frames; features and the
+    pooled [100 + 576, 1024] video tokens vs the CPU oracle."""
+    cfg = synth.CLIP_L14_336
+    w = synth.make_clip_weights(cfg, seed=3)
+    tower = _tower(cfg, w, dtype)
+    frames = synth.make_frames(3, 336, seed=4)
+    px = ovis.clip_preprocess(frames)
+    feat = tower(ctx.preprocess_u8(torch.from_numpy(frames).to(DEV), dtype), output_hidden_states=True).hidden_states[-2][:, 1:]
+    assert tuple(feat.shape) == (3, 576, 1024)
+    ref = ovis.clip_select_features(px, w, cfg)
+    e = rel(feat, ref)
+    print(f"ViT-L/14-336 3 frames {dtype}: normwise rel err vs fp32 oracle = {e:.3e}")
+    assert e < tol
+    pooled = ctx.st_pool(feat)
+    assert tuple(pooled.shape) == (676, 1024) and not pooled[3:100].any()
+    assert rel(pooled, ovis.spatio_temporal_pool_torch(ref)) < tol
+
+
 def test_vit_100_frames_properties(ctx):
     """BASELINE config 2 size (100 frames): size-independent properties -- frames are independent, so a batch
     split (the reference's infer_batch=32 loop, save_spatio_temporal_clip_features.py:108-121) or a frame permutation
