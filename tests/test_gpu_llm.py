@@ -114,6 +114,32 @@ def test_ragged_batch_matches_single(ctx, golden_dir):
             assert singles[i] == ref
 
 
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+def test_ragged_batch_random_shapes(ctx, seed):
+    """Randomised version of the property above: 1..16 sequences, prompt lengths from a few tokens to several prefill-attention chunks
+    (64-key chunks, 128-query blocks), so prompts end on both sides of every tiling boundary; greedy tokens of the batch == single runs."""
+    cfg = synth.LLAMA_TINY
+    w = synth.make_llama_weights(cfg, seed=3, head_std=0.08)
+    m = _model(cfg, w, torch.float16)
+    rng = np.random.default_rng(seed)
+    PATCH, START, END = cfg.vocab - 3, cfg.vocab - 2, cfg.vocab - 1
+    V = 20
+    B = int(rng.integers(1, 17))
+    prompts, feats = [], []
+    for b in range(B):
+        head = rng.integers(1, cfg.vocab - 3, int(rng.integers(1, 260))).tolist()
+        tail = rng.integers(1, cfg.vocab - 3, int(rng.integers(1, 40))).tolist()
+        prompts.append([1] + head + [START] + [PATCH] * V + [END] + tail)
+        feats.append(torch.from_numpy(rng.standard_normal((V, 1024), dtype=np.float32)))
+    feats_t = torch.stack(feats).half()
+    n = 7
+    batch = m.generate(prompts, video_spatio_temporal_features=feats_t, max_new_tokens=n)
+    for i in rng.permutation(B)[:5]:                      # single-sequence reruns of up to five of them
+        p = prompts[i]
+        single = m.generate([p], video_spatio_temporal_features=feats_t[i:i + 1], max_new_tokens=n)[0, len(p):].tolist()
+        assert batch[i, len(p):len(p) + n].tolist() == single, (seed, B, i, len(p))
+
+
 @pytest.mark.parametrize("shape", ["7b", "13b"])
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 3e-3), (torch.bfloat16, 2.4e-2)])
 def test_7b_shaped_two_layers_vs_oracle(ctx, dtype, tol, shape):
