@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PGV_VERSION 100
+#define PGV_VERSION 200
 
 enum { PGV_OK = 0, PGV_EINVAL = 1, PGV_EHIP = 2, PGV_ENOMEM = 3, PGV_ESTATE = 4, PGV_ENAME = 5 };
 enum { PGV_F16 = 0, PGV_BF16 = 1, PGV_F32 = 2 };
@@ -77,9 +77,10 @@ void pgv_vit_destroy(pgv_vit *vit);
 /* Load one tensor by its HF state-dict name ("vision_model.encoder.layers.3.mlp.fc1.weight" ...;
  * the "vision_model." prefix is optional).  `data` is contiguous in `src_dtype`, on the device if
  * `on_device` else on the host.  The library converts/re-lays it out into its packed storage
- * (fused qkv, K-padded patch filter, fp32 biases and norm parameters).  Replaces
+ * (fused qkv, K-padded patch filter, fp32 biases and norm parameters).  `numel` is the element count of `data`: a tensor whose size
+ * disagrees with the shape the config implies is rejected with PGV_EINVAL (torch's "size mismatch"), never read past its end.  Replaces
  * CLIPVisionModel.from_pretrained(...) at video_chatgpt/eval/model_utils.py:134-136. */
-int pgv_vit_load_tensor(pgv_vit *vit, const char *name, const void *data, int src_dtype, int on_device, void *stream);
+int pgv_vit_load_tensor(pgv_vit *vit, const char *name, const void *data, int src_dtype, int on_device, int64_t numel, void *stream);
 /* number of tensors still missing (0 = ready) */
 int pgv_vit_missing(const pgv_vit *vit);
 
@@ -87,6 +88,11 @@ int pgv_vit_missing(const pgv_vit *vit);
  * size) -> (x/255 - mean)/std in NCHW 16-bit, i.e. CLIPImageProcessor.preprocess(...).half()
  * (video_chatgpt/inference.py:86-89) for crop-sized input. */
 int pgv_preprocess_u8(pgv_ctx *ctx, const uint8_t *d_frames, int T, int image, int dtype, void *d_pixels, void *stream);
+/* Frame ingest at native resolution: uint8 RGB frames [T, H, W, 3] as the video decoder delivers them -> nearest
+ * resize to image x image exactly as load_video does it (video_chatgpt/eval/model_utils.py:38-43: permute, .float(),
+ * F.interpolate(size) with the default mode 'nearest' -> source index min(floorf(dst * (float)in / out), in - 1) per axis, cast back
+ * to uint8) -> CLIPImageProcessor normalisation -> NCHW 16-bit, in one pass.  H == W == image reduces to pgv_preprocess_u8. */
+int pgv_ingest_u8(pgv_ctx *ctx, const uint8_t *d_frames, int T, int H, int W, int image, int dtype, void *d_pixels, void *stream);
 
 /* hidden_states[k] of the tower for k = n_layers (k=0: pre-LayerNorm'ed embeddings):
  * d_pixels [T,3,image,image] 16-bit NCHW -> d_hidden [T, patches+1, hidden] 16-bit.
@@ -133,11 +139,11 @@ void pgv_llm_destroy(pgv_llm *llm);
 /* HF names: "model.embed_tokens.weight", "model.layers.N.self_attn.q_proj.weight", ...,
  * "model.norm.weight", "lm_head.weight".  `model.embed_tokens.weight` may be re-loaded later (the
  * projector checkpoint carries the rows of the added video tokens, train/llava_trainer.py:34). */
-int pgv_llm_load_tensor(pgv_llm *llm, const char *name, const void *data, int src_dtype, int on_device, void *stream);
+int pgv_llm_load_tensor(pgv_llm *llm, const char *name, const void *data, int src_dtype, int on_device, int64_t numel, void *stream);
 int pgv_llm_missing(const pgv_llm *llm);
 /* Load `nrows` rows starting at `row0` of "model.embed_tokens.weight" or "lm_head.weight" (checkpoints whose
  * vocabulary is smaller than the resized model, eval/model_utils.py:119-127). */
-int pgv_llm_load_rows(pgv_llm *llm, const char *name, const void *data, int src_dtype, int on_device, int row0, int nrows, void *stream);
+int pgv_llm_load_rows(pgv_llm *llm, const char *name, const void *data, int src_dtype, int on_device, int row0, int nrows, int64_t numel, void *stream);
 /* model.resize_token_embeddings(n) (eval/model_utils.py:119): the handle is allocated with 64 spare vocabulary
  * rows; growing within them zero-fills the new embed / lm_head rows (the projector checkpoint then overwrites them). */
 int pgv_llm_resize_vocab(pgv_llm *llm, int new_vocab, void *stream);
@@ -177,6 +183,21 @@ int pgv_llm_decode(pgv_ctx *ctx, pgv_llm *llm, pgv_kv *kv, const int32_t *d_last
  * do_sample=False. */
 int pgv_llm_decode_greedy(pgv_ctx *ctx, pgv_llm *llm, pgv_kv *kv, const int32_t *d_first, int n, int eos_id,
                           int32_t *d_tokens, void *stream);
+
+/* Sampling (the reference's DEFAULT decode mode: model.generate(do_sample=True, temperature=0.2), video_chatgpt/inference.py:106-112;
+ * HF's sample loop = TemperatureLogitsWarper, TopKLogitsWarper(top_k=50 from the default GenerationConfig), softmax, multinomial).
+ * The multinomial draw is an inverse-CDF pick with a caller-supplied uniform u in [0,1): token = the first vocabulary index whose
+ * cumulative probability exceeds u; probabilities = softmax(logits / temperature) over the top_k largest logits (top_k <= 0: all of
+ * them; ties at the k-th value are kept, as HF's `scores < kth` mask does).  The token stays on the device.
+ * pgv_llm_sample: pick from the logits of the last prefill / decode call of `kv` with d_u [B]; the result replaces the greedy pick
+ * as the cache's current token and is written to d_next [B] (may be NULL). */
+int pgv_llm_sample(pgv_ctx *ctx, pgv_llm *llm, pgv_kv *kv, float temperature, int top_k, const float *d_u, int32_t *d_next, void *stream);
+/* n sampled steps without host round trips (twin of pgv_llm_decode_greedy): step i draws with d_u[i * B + b]. */
+int pgv_llm_decode_sample(pgv_ctx *ctx, pgv_llm *llm, pgv_kv *kv, const int32_t *d_first, int n, int eos_id, float temperature, int top_k,
+                          const float *d_u, int32_t *d_tokens, void *stream);
+/* building block: the same pick on caller logits [B, V] fp32 (row stride V) */
+int pgv_sample_logits(pgv_ctx *ctx, const float *d_logits, int V, int B, float temperature, int top_k, const float *d_u, int32_t *d_next,
+                      void *stream);
 
 /* current length (tokens in cache) of sequence b, host-side bookkeeping */
 int pgv_kv_len(const pgv_kv *kv, int b);

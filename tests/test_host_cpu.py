@@ -27,7 +27,7 @@ def test_library_builds_and_exports_every_header_symbol():
         assert name in _lib.PROTOTYPES, f"ctypes binding lacks {name}"
     assert set(_lib.PROTOTYPES) <= declared | {"pgv_version"}
     lib.pgv_version.restype = ctypes.c_int
-    assert lib.pgv_version() == 100
+    assert lib.pgv_version() == _lib.ABI_VERSION
 
 
 def test_product_path_fails_loudly_without_gpu():

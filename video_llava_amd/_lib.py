@@ -15,6 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpgv.so")
 
+ABI_VERSION = 200          # PGV_VERSION of include/pgv.h this table was written against
 PGV_OK, PGV_EINVAL, PGV_EHIP, PGV_ENOMEM, PGV_ESTATE, PGV_ENAME = 0, 1, 2, 3, 4, 5
 PGV_F16, PGV_BF16, PGV_F32 = 0, 1, 2
 EPI_NONE, EPI_BIAS, EPI_BIAS_QGELU, EPI_BIAS_GELU, EPI_RESID, EPI_BIAS_RESID, EPI_SWIGLU, EPI_F32 = range(8)
@@ -46,7 +47,7 @@ PROTOTYPES = {
     "pgv_prof_calibrate": (_i, [_vp, _vp, _i, C.POINTER(C.c_double)]),
     "pgv_vit_create": (_i, [_vp, C.POINTER(VitConfig), _i, C.POINTER(_vp)]),
     "pgv_vit_destroy": (None, [_vp]),
-    "pgv_vit_load_tensor": (_i, [_vp, C.c_char_p, _vp, _i, _i, _vp]),
+    "pgv_vit_load_tensor": (_i, [_vp, C.c_char_p, _vp, _i, _i, _i64, _vp]),
     "pgv_vit_missing": (_i, [_vp]),
     "pgv_preprocess_u8": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "pgv_vit_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
@@ -54,9 +55,9 @@ PROTOTYPES = {
     "pgv_projector": (_i, [_vp, _i, _i, C.POINTER(_vp), C.POINTER(_vp), _i, _i, _vp, _i, _vp, _vp]),
     "pgv_llm_create": (_i, [_vp, C.POINTER(LlmConfig), _i, C.POINTER(_vp)]),
     "pgv_llm_destroy": (None, [_vp]),
-    "pgv_llm_load_tensor": (_i, [_vp, C.c_char_p, _vp, _i, _i, _vp]),
+    "pgv_llm_load_tensor": (_i, [_vp, C.c_char_p, _vp, _i, _i, _i64, _vp]),
     "pgv_llm_missing": (_i, [_vp]),
-    "pgv_llm_load_rows": (_i, [_vp, C.c_char_p, _vp, _i, _i, _i, _i, _vp]),
+    "pgv_llm_load_rows": (_i, [_vp, C.c_char_p, _vp, _i, _i, _i, _i, _i64, _vp]),
     "pgv_llm_resize_vocab": (_i, [_vp, _i, _vp]),
     "pgv_llm_vocab": (_i, [_vp]),
     "pgv_kv_create": (_i, [_vp, _vp, _i, _i, C.POINTER(_vp)]),
@@ -65,6 +66,10 @@ PROTOTYPES = {
     "pgv_llm_prefill": (_i, [_vp, _vp, _vp, _vp, C.POINTER(C.c_int32), _i, _vp, _i, C.POINTER(C.c_int32), _vp, _vp, _vp]),
     "pgv_llm_decode": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pgv_llm_decode_greedy": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "pgv_llm_sample": (_i, [_vp, _vp, _vp, _f, _i, _vp, _vp, _vp]),
+    "pgv_llm_decode_sample": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp]),
+    "pgv_sample_logits": (_i, [_vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp]),
+    "pgv_ingest_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "pgv_gemm": (_i, [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pgv_vit_attention": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pgv_gemv": (_i, [_vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
@@ -99,8 +104,9 @@ def load(build_if_missing: bool = True) -> C.CDLL:
             fn = getattr(lib, name)          # AttributeError = header/library mismatch: fail loudly
             fn.restype = res
             fn.argtypes = args
-        if lib.pgv_version() != 100:
-            raise RuntimeError(f"libpgv version {lib.pgv_version()} does not match the binding (100)")
+        if lib.pgv_version() != ABI_VERSION:
+            raise RuntimeError(f"libpgv version {lib.pgv_version()} does not match the binding ({ABI_VERSION}); rebuild with "
+                               "`python -m video_llava_amd.build --force`")
         _lib = lib
         return lib
 
@@ -222,6 +228,24 @@ class Context:
         out = torch.empty(n_temporal + P, Cc, dtype=out_dtype, device=feats.device)
         check(self.lib.pgv_st_pool(self.handle, feats.data_ptr(), dtype_code(feats.dtype), T, P, Cc, feats.stride(0), n_temporal,
                                    out.data_ptr(), dtype_code(out_dtype), stream_ptr(feats.device)), "pgv_st_pool")
+        return out
+
+    def ingest_u8(self, frames: torch.Tensor, size: int, dtype: torch.dtype) -> torch.Tensor:
+        """uint8 [T, H, W, 3] on the device at native resolution -> nearest resize (load_video's rule) + CLIP normalisation -> [T, 3, size, size]."""
+        assert frames.is_cuda and frames.dtype == torch.uint8 and frames.is_contiguous() and frames.dim() == 4 and frames.shape[-1] == 3
+        T, H, W = frames.shape[0], frames.shape[1], frames.shape[2]
+        out = torch.empty(T, 3, size, size, dtype=dtype, device=frames.device)
+        check(self.lib.pgv_ingest_u8(self.handle, frames.data_ptr(), T, H, W, size, dtype_code(dtype), out.data_ptr(),
+                                     stream_ptr(frames.device)), "pgv_ingest_u8")
+        return out
+
+    def sample_logits(self, logits: torch.Tensor, u: torch.Tensor, temperature: float, top_k: int = 50) -> torch.Tensor:
+        """Inverse-CDF pick from softmax(logits / temperature) restricted to the top_k logits (<= 0: all) with uniforms u [B] -> int32 [B]."""
+        assert logits.is_cuda and logits.dtype == torch.float32 and logits.is_contiguous() and logits.dim() == 2
+        assert u.is_cuda and u.dtype == torch.float32 and u.is_contiguous() and u.numel() == logits.shape[0]
+        out = torch.empty(logits.shape[0], dtype=torch.int32, device=logits.device)
+        check(self.lib.pgv_sample_logits(self.handle, logits.data_ptr(), logits.shape[1], logits.shape[0], float(temperature), int(top_k),
+                                         u.data_ptr(), out.data_ptr(), stream_ptr(logits.device)), "pgv_sample_logits")
         return out
 
     def preprocess_u8(self, frames: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:

@@ -54,7 +54,7 @@ class VideoChatGPTInterface:
         from .feature_extraction import load_video
         from .inference import video_features
         if isinstance(video_path, str):
-            frames = load_video(video_path, shape=self.frame_size)
+            frames = load_video(video_path, shape=self.frame_size, device_resize=True)
         elif hasattr(video_path, "shape"):                 # uint8 [T, H, W, 3] frames handed over directly
             frames = video_path
         else:

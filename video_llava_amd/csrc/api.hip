@@ -46,6 +46,7 @@ extern "C" void pgv_ctx_destroy(pgv_ctx* ctx) {
     if (ctx->ws) (void)hipFree(ctx->ws);
     if (ctx->zero_bias) (void)hipFree(ctx->zero_bias);
     if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
+    if (ctx->ws_event) (void)hipEventDestroy(ctx->ws_event);
     for (auto& f : ctx->fam)
         for (auto e : f.ev) (void)hipEventDestroy(e);
     delete ctx;
@@ -53,8 +54,14 @@ extern "C" void pgv_ctx_destroy(pgv_ctx* ctx) {
 
 extern "C" size_t pgv_ctx_workspace_bytes(const pgv_ctx* ctx) { return ctx ? ctx->ws_bytes : 0; }
 
-int pgv_ws_reserve(pgv_ctx* ctx, size_t bytes) {
+int pgv_ws_reserve(pgv_ctx* ctx, size_t bytes, hipStream_t s) {
     ctx->ws_off = 0;
+    if (ctx->ws_stream_valid && ctx->ws_stream != s) {
+        if (!ctx->ws_event) PGV_HIP(hipEventCreateWithFlags(&ctx->ws_event, hipEventDisableTiming));
+        if (hipEventRecord(ctx->ws_event, ctx->ws_stream) == hipSuccess) PGV_HIP(hipStreamWaitEvent(s, ctx->ws_event, 0));
+        else (void)hipGetLastError();          // the previous stream no longer exists: its work was drained when it was destroyed
+    }
+    ctx->ws_stream = s; ctx->ws_stream_valid = true;
     if (bytes <= ctx->ws_bytes) return PGV_OK;
     // grow: wait for queued work that may still read the old arena
     PGV_HIP(hipDeviceSynchronize());

@@ -115,17 +115,25 @@ __global__ __launch_bounds__(256) void cast_kernel(const f32x4_t* __restrict__ x
 }
 
 // ---------------------------------------------------------------------------------------------
-// frame preprocessing: uint8 [T,S,S,3] -> (x/255 - mean)/std, NCHW 16-bit
-// (CLIPImageProcessor.preprocess for crop-sized frames + .half(), video_chatgpt/inference.py:86-89)
+// frame ingest: uint8 [T,H,W,3] at native resolution -> nearest resize to S x S -> (x/255 - mean)/std, NCHW 16-bit.
+//   resize   = load_video (video_chatgpt/eval/model_utils.py:38-43): .float(), F.interpolate(size=...) in its default mode 'nearest',
+//              back to uint8.  PyTorch's index rule (ATen UpSample.h nearest_neighbor_compute_source_index): with the fp32 scale
+//              (float)in / out, src = min((int)floorf(dst * scale), in - 1); nearest sampling copies bytes, so the float round trip is exact.
+//   normalise = CLIPImageProcessor.preprocess for crop-sized frames + .half() (video_chatgpt/inference.py:86-89).
+// The scales are computed on the host with the same fp32 division and passed in, the per-pixel product dst * scale is one exactly
+// rounded fp32 multiply on both sides.  H == W == S is the identity map (scale 1).
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(256) void preprocess_kernel(const uint8_t* __restrict__ in, typename T::elem* __restrict__ out,
-                                                         int total_px, int hw) {
+__global__ __launch_bounds__(256) void ingest_kernel(const uint8_t* __restrict__ in, typename T::elem* __restrict__ out, int total_px, int S, int H, int W,
+                                                     float scale_h, float scale_w) {
     const float mean[3] = {0.48145466f, 0.4578275f, 0.40821073f};
     const float stdv[3] = {0.26862954f, 0.26130258f, 0.27577711f};
+    const int hw = S * S;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total_px; i += gridDim.x * 256) {
         const int t = i / hw, p = i - t * hw;
-        const uint8_t* px = in + (size_t)i * 3;
+        const int y = p / S, x = p - y * S;
+        const int sy = min((int)floorf((float)y * scale_h), H - 1), sx = min((int)floorf((float)x * scale_w), W - 1);
+        const uint8_t* px = in + (((size_t)t * H + sy) * W + sx) * 3;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             float v = (float)px[c] * (1.0f / 255.0f);
@@ -250,15 +258,21 @@ extern "C" int pgv_rmsnorm(pgv_ctx* ctx, int dtype, const float* d_x, const floa
     return pgv_launch_rmsnorm(dtype, d_x, d_gamma, eps, d_y, rows, cols, (hipStream_t)stream);
 }
 
-extern "C" int pgv_preprocess_u8(pgv_ctx* ctx, const uint8_t* d_frames, int T, int image, int dtype, void* d_pixels, void* stream) {
-    PGV_CHECK(ctx && d_frames && d_pixels && T > 0 && image > 0, "pgv_preprocess_u8: bad arguments");
-    const int hw = image * image;
-    const long long total = (long long)T * hw;
-    PGV_CHECK(total < (1ll << 31), "pgv_preprocess_u8: too many pixels");
+extern "C" int pgv_ingest_u8(pgv_ctx* ctx, const uint8_t* d_frames, int T, int H, int W, int image, int dtype, void* d_pixels, void* stream) {
+    PGV_CHECK(ctx && d_frames && d_pixels && T > 0 && H > 0 && W > 0 && image > 0, "pgv_ingest_u8: bad arguments");
+    const long long total = (long long)T * image * image;
+    PGV_CHECK(total < (1ll << 31), "pgv_ingest_u8: too many pixels");
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    PGV_DISPATCH_DTYPE(dtype, Tt, hipLaunchKernelGGL((preprocess_kernel<Tt>), dim3(grid), dim3(256), 0, (hipStream_t)stream, d_frames,
-                                                     (typename Tt::elem*)d_pixels, (int)total, hw));
+    // compute_scales_value<float>(nullopt, in, out) of ATen: static_cast<float>(in) / out, an fp32 division
+    const float scale_h = (float)H / (float)image, scale_w = (float)W / (float)image;
+    PGV_DISPATCH_DTYPE(dtype, Tt, hipLaunchKernelGGL((ingest_kernel<Tt>), dim3(grid), dim3(256), 0, (hipStream_t)stream, d_frames,
+                                                     (typename Tt::elem*)d_pixels, (int)total, image, H, W, scale_h, scale_w));
+    PGV_HIP(hipGetLastError());
     return PGV_OK;
+}
+
+extern "C" int pgv_preprocess_u8(pgv_ctx* ctx, const uint8_t* d_frames, int T, int image, int dtype, void* d_pixels, void* stream) {
+    return pgv_ingest_u8(ctx, d_frames, T, image, image, image, dtype, d_pixels, stream);
 }
 
 extern "C" int pgv_st_pool(pgv_ctx* ctx, const void* d_feats, int in_dtype, int T, int P, int C, int64_t frame_stride, int n_temporal,

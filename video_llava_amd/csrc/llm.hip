@@ -26,9 +26,11 @@ int pgv_launch_decode_attn(pgv_ctx* ctx, int dtype, const void* qkv, const int* 
                            int heads, int max_seq, double bytes, hipStream_t s);
 int pgv_launch_argmax(const float* logits, int V, int B, int* next, int* pos, int* step, int* hist, int hist_stride, int* done, int eos, int flags,
                       hipStream_t s);
+int pgv_launch_sample(const float* logits, int V, int B, float temperature, int top_k, const float* u, int u_stride, int u_by_step, int* next, int* pos,
+                      int* step, int* hist, int hist_stride, int* done, int eos, int advance, hipStream_t s);
 enum { GV_STORE16 = 0, GV_RESID = 1, GV_SWIGLU = 2, GV_F32 = 3, GV_PART = 4 };
 constexpr int kSplits = 2;      // split-K of the residual GEMVs (o_proj, down_proj) in decode
-enum { AM_INC_POS = 1, AM_RECORD = 2 };
+enum { AM_INC_POS = 1, AM_RECORD = 2, AM_SAMPLE = 4 };
 
 constexpr int kMaxPos = 4096;   // max_position_embeddings of LLaVA-1.5 / Vicuna-1.5
 constexpr int kHD = 128;
@@ -57,6 +59,7 @@ struct pgv_llm {
     char* blob8 = nullptr;   // fp8 copies + scales (decode weight stream halves; the 16-bit copies hold the dequantised values)
     void* q_head = nullptr; float* s_head = nullptr;
     bool fp8 = false;
+    int generation = 0;      // bumped by every call that changes what a captured decode graph baked in (vocabulary size, weight pointers)
 };
 
 struct pgv_kv {
@@ -73,7 +76,10 @@ struct pgv_kv {
     // one decode step captured as a hipGraph (all kernel arguments are fixed device addresses; positions, current
     // tokens and step counters live in device memory and are advanced by the argmax kernel)
     hipGraphExec_t gexec = nullptr;
-    int g_B = 0, g_eos = 0, g_flags = 0;
+    int g_B = 0, g_eos = 0, g_flags = 0, g_gen = -1, g_topk = 0;
+    float g_temp = 0.f;
+    float* d_u = nullptr;               // uniforms of a sampled decode run: [max_seq][B], indexed by the device-side step counter
+    float s_temp = 1.f; int s_topk = 0; // sampling parameters of the run in flight (AM_SAMPLE)
     bool warmed = false;
 };
 
@@ -139,19 +145,27 @@ extern "C" int pgv_llm_vocab(const pgv_llm* llm) { return llm ? llm->cfg.vocab :
 extern "C" int pgv_llm_resize_vocab(pgv_llm* m, int new_vocab, void* stream) {
     PGV_CHECK(m != nullptr, "pgv_llm_resize_vocab: null model");
     PGV_CHECK(new_vocab >= 1 && new_vocab <= m->vocab_cap, "pgv_llm_resize_vocab: %d outside [1,%d] (64 spare rows are allocated at creation)", new_vocab, m->vocab_cap);
+    if (new_vocab == m->cfg.vocab) return PGV_OK;
+    if (m->fp8) { pgv_set_error("pgv_llm_resize_vocab: the weights are already quantised to fp8; resize before pgv_llm_quantize_fp8"); return PGV_ESTATE; }
     const size_t H = m->cfg.hidden;
     if (new_vocab > m->cfg.vocab) {
         const size_t off = (size_t)m->cfg.vocab * H * 2, bytes = (size_t)(new_vocab - m->cfg.vocab) * H * 2;
         PGV_HIP(hipMemsetAsync((char*)m->embed + off, 0, bytes, (hipStream_t)stream));
-        // lm_head is fragment-blocked (rows interleaved inside 1 KiB blocks); its spare rows were zeroed at creation
+        // lm_head is fragment-blocked (rows interleaved inside 1 KiB blocks): zero the new rows in place (a shrink followed by a
+        // grow must not resurrect old rows)
+        PGV_TRY(pgv_zero_rows_blocked(m->lm_head, m->cfg.vocab, new_vocab - m->cfg.vocab, (long long)H, (hipStream_t)stream));
     }
     m->cfg.vocab = new_vocab;
+    m->generation += 1;           // captured decode graphs have the old vocabulary baked into lm_head / the token pick
     return PGV_OK;
 }
 
-extern "C" int pgv_llm_load_rows(pgv_llm* m, const char* name, const void* data, int src_dtype, int on_device, int row0, int nrows, void* stream) {
+extern "C" int pgv_llm_load_rows(pgv_llm* m, const char* name, const void* data, int src_dtype, int on_device, int row0, int nrows, int64_t numel, void* stream) {
     PGV_CHECK(m && name && data, "pgv_llm_load_rows: null argument");
     PGV_CHECK(row0 >= 0 && nrows >= 1 && row0 + nrows <= m->cfg.vocab, "pgv_llm_load_rows: rows [%d,%d) outside the vocabulary (%d)", row0, row0 + nrows, m->cfg.vocab);
+    PGV_CHECK(numel == (int64_t)nrows * m->cfg.hidden, "pgv_llm_load_rows: size mismatch for '%s': %lld elements given for %d rows of %d", name, (long long)numel,
+              nrows, m->cfg.hidden);
+    if (m->fp8) { pgv_set_error("pgv_llm_load_rows: the weights are quantised to fp8 (the fp8 copies would go stale); load into a fresh model"); return PGV_ESTATE; }
     PackDst d;
     d.dst_dtype = m->dtype; d.rows = nrows; d.cols = m->cfg.hidden; d.dst_stride = d.cols; d.row_off = row0;
     if (!strcmp(name, "model.embed_tokens.weight")) d.ptr = m->embed;
@@ -162,8 +176,9 @@ extern "C" int pgv_llm_load_rows(pgv_llm* m, const char* name, const void* data,
     return PGV_OK;
 }
 
-extern "C" int pgv_llm_load_tensor(pgv_llm* m, const char* name_in, const void* data, int src_dtype, int on_device, void* stream) {
+extern "C" int pgv_llm_load_tensor(pgv_llm* m, const char* name_in, const void* data, int src_dtype, int on_device, int64_t numel, void* stream) {
     PGV_CHECK(m && name_in && data, "pgv_llm_load_tensor: null argument");
+    if (m->fp8) { pgv_set_error("pgv_llm_load_tensor: the weights are quantised to fp8 (the fp8 copies would go stale); load into a fresh model"); return PGV_ESTATE; }
     std::string name(name_in);
     const long long H = m->cfg.hidden, I = m->cfg.inter, V = m->cfg.vocab;
     PackDst d;
@@ -192,6 +207,8 @@ extern "C" int pgv_llm_load_tensor(pgv_llm* m, const char* name_in, const void* 
         else { pgv_set_error("pgv_llm_load_tensor: unexpected key '%s'", name_in); return PGV_ENAME; }
     } else { pgv_set_error("pgv_llm_load_tensor: unexpected key '%s'", name_in); return PGV_ENAME; }
     d.dst_stride = d.cols;
+    PGV_CHECK(numel == d.rows * d.cols, "pgv_llm_load_tensor: size mismatch for '%s': %lld elements given, the model expects %lld x %lld", name_in,
+              (long long)numel, d.rows, d.cols);
     PGV_TRY(pgv_pack_tensor(d, data, src_dtype, on_device, (hipStream_t)stream));
     m->loaded.insert(name);
     return PGV_OK;
@@ -232,6 +249,7 @@ extern "C" int pgv_llm_quantize_fp8(pgv_ctx* ctx, pgv_llm* m, void* stream) {
     }
     PGV_HIP(hipStreamSynchronize(s));
     m->fp8 = true;
+    m->generation += 1;           // decode graphs captured before now stream the 16-bit matrices
     return PGV_OK;
 }
 
@@ -278,7 +296,8 @@ extern "C" int pgv_kv_create(pgv_ctx* ctx, pgv_llm* llm, int batch, int max_seq,
     auto take = [&](size_t bytes) { size_t o = off; off += pgv_align(bytes); return o; };
     const size_t o_cache = take(per * 2 * L);
     const size_t o_resid = take(B * H * 4), o_xn = take(B * H * 2), o_qkv = take(B * 3 * H * 2), o_ao = take(B * H * 2), o_act = take(B * I * 2),
-                 o_logits = take(B * V * 4), o_part = take((size_t)kSplits * B * H * 4), o_ints = take((4 * B + B * (size_t)max_seq) * 4);
+                 o_logits = take(B * V * 4), o_part = take((size_t)kSplits * B * H * 4), o_ints = take((4 * B + B * (size_t)max_seq) * 4),
+                 o_u = take(B * (size_t)max_seq * 4);
     hipError_t e = hipMalloc((void**)&kv->blob, off);
     if (e != hipSuccess) { delete kv; pgv_set_error("pgv_kv_create: hipMalloc(%zu MiB): %s", off >> 20, hipGetErrorString(e)); return PGV_ENOMEM; }
     char* b = kv->blob;
@@ -286,6 +305,7 @@ extern "C" int pgv_kv_create(pgv_ctx* ctx, pgv_llm* llm, int batch, int max_seq,
     kv->resid = (float*)(b + o_resid); kv->xn = b + o_xn; kv->qkv = b + o_qkv; kv->ao = b + o_ao; kv->act = b + o_act; kv->logits = (float*)(b + o_logits); kv->part = (float*)(b + o_part);
     int* ints = (int*)(b + o_ints);
     kv->d_pos = ints; kv->d_cur = ints + B; kv->d_step = ints + 2 * B; kv->d_done = ints + 3 * B; kv->d_hist = ints + 4 * B;
+    kv->d_u = (float*)(b + o_u);
     e = hipMemset(ints, 0, (4 * B + B * (size_t)max_seq) * 4);
     if (e != hipSuccess) { (void)hipFree(kv->blob); delete kv; pgv_set_error("pgv_kv_create: memset: %s", hipGetErrorString(e)); return PGV_EHIP; }
     kv->h_len.assign(batch, 0);
@@ -312,7 +332,11 @@ static int lm_head_and_pick(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int B, int eos
     pgv_prof_end(ctx, 6, s, 0.0, 0.0);
     PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_F32, m->fp8 ? m->q_head : m->lm_head, kv->xn, H, kv->logits, V, V, H, B, s, 1, m->fp8 ? m->s_head : nullptr));
     pgv_prof_begin(ctx, 6, s);
-    PGV_TRY(pgv_launch_argmax(kv->logits, V, B, kv->d_cur, kv->d_pos, kv->d_step, kv->d_hist, kv->max_seq, kv->d_done, eos, flags, s));
+    if (flags & AM_SAMPLE)
+        PGV_TRY(pgv_launch_sample(kv->logits, V, B, kv->s_temp, kv->s_topk, kv->d_u, B, 1, kv->d_cur, kv->d_pos, kv->d_step, kv->d_hist, kv->max_seq, kv->d_done,
+                                  eos, flags & (AM_INC_POS | AM_RECORD), s));
+    else
+        PGV_TRY(pgv_launch_argmax(kv->logits, V, B, kv->d_cur, kv->d_pos, kv->d_step, kv->d_hist, kv->max_seq, kv->d_done, eos, flags, s));
     pgv_prof_end(ctx, 6, s, 0.0, 0.0);
     return PGV_OK;
 }
@@ -356,7 +380,7 @@ extern "C" int pgv_llm_prefill(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, const int32
 
     const size_t b_meta = pgv_align(meta.size() * 4), b_resid = pgv_align((size_t)M * H * 4), b_xn = pgv_align((size_t)M * H * 2),
                  b_qkv = pgv_align((size_t)M * 3 * H * 2), b_ao = pgv_align((size_t)M * H * 2), b_act = pgv_align((size_t)M * I * 2);
-    PGV_TRY(pgv_ws_reserve(ctx, b_meta + b_resid + b_xn + b_qkv + b_ao + b_act));
+    PGV_TRY(pgv_ws_reserve(ctx, b_meta + b_resid + b_xn + b_qkv + b_ao + b_act, s));
     int* d_meta = (int*)pgv_ws_alloc(ctx, b_meta);
     float* resid = (float*)pgv_ws_alloc(ctx, b_resid);
     char* xn = (char*)pgv_ws_alloc(ctx, b_xn);
@@ -444,7 +468,8 @@ static int decode_step(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int eos, int flags,
         kv->warmed = true;
         PGV_TRY(decode_enqueue(ctx, m, kv, eos, flags, s));
     } else {
-        if (!kv->gexec || kv->g_B != B || kv->g_eos != eos || kv->g_flags != flags) {
+        if (!kv->gexec || kv->g_B != B || kv->g_eos != eos || kv->g_flags != flags || kv->g_gen != m->generation ||
+            ((flags & AM_SAMPLE) && (kv->g_temp != kv->s_temp || kv->g_topk != kv->s_topk))) {
             if (kv->gexec) { (void)hipGraphExecDestroy(kv->gexec); kv->gexec = nullptr; }
             // capture on a library-owned stream (the caller's may be the legacy default stream, which cannot be
             // captured); capture executes nothing, the instantiated graph is then launched on the caller's stream
@@ -458,7 +483,7 @@ static int decode_step(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int eos, int flags,
             e = hipGraphInstantiate(&kv->gexec, graph, nullptr, nullptr, 0);
             (void)hipGraphDestroy(graph);
             if (e != hipSuccess) { kv->gexec = nullptr; pgv_set_error("decode graph instantiate failed: %s", hipGetErrorString(e)); return PGV_EHIP; }
-            kv->g_B = B; kv->g_eos = eos; kv->g_flags = flags;
+            kv->g_B = B; kv->g_eos = eos; kv->g_flags = flags; kv->g_gen = m->generation; kv->g_temp = kv->s_temp; kv->g_topk = kv->s_topk;
         }
         PGV_HIP(hipGraphLaunch(kv->gexec, s));
     }
@@ -501,6 +526,37 @@ extern "C" int pgv_llm_decode_greedy(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, const
     return PGV_OK;
 }
 
+extern "C" int pgv_llm_sample(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, float temperature, int top_k, const float* d_u, int32_t* d_next, void* stream) {
+    PGV_CHECK(ctx && d_u, "pgv_llm_sample: null argument");
+    PGV_CHECK(m && kv && kv->llm == m, "pgv_llm_sample: bad model / cache");
+    if (kv->active < 1) { pgv_set_error("pgv_llm_sample: no prefilled sequences in this cache"); return PGV_ESTATE; }
+    hipStream_t s = (hipStream_t)stream;
+    const int B = kv->active;
+    PGV_TRY(pgv_launch_sample(kv->logits, m->cfg.vocab, B, temperature, top_k, d_u, B, 0, kv->d_cur, kv->d_pos, kv->d_step, kv->d_hist, kv->max_seq, kv->d_done,
+                              -1, 0, s));
+    if (d_next) PGV_HIP(hipMemcpyAsync(d_next, kv->d_cur, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
+
+extern "C" int pgv_llm_decode_sample(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, const int32_t* d_first, int n, int eos_id, float temperature, int top_k,
+                                     const float* d_u, int32_t* d_tokens, void* stream) {
+    PGV_CHECK(ctx && d_first && d_tokens && d_u, "pgv_llm_decode_sample: null argument");
+    PGV_CHECK(n >= 1, "pgv_llm_decode_sample: n must be positive");
+    PGV_CHECK(temperature > 0.f, "pgv_llm_decode_sample: temperature must be positive (got %g)", (double)temperature);
+    PGV_TRY(check_decode(m, kv, n, "pgv_llm_decode_sample"));
+    hipStream_t s = (hipStream_t)stream;
+    const int B = kv->active;
+    if (d_first != kv->d_cur) PGV_HIP(hipMemcpyAsync(kv->d_cur, d_first, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+    PGV_HIP(hipMemsetAsync(kv->d_step, 0, (size_t)kv->B * 4, s));
+    PGV_HIP(hipMemcpyAsync(kv->d_u, d_u, (size_t)n * B * 4, hipMemcpyDeviceToDevice, s));     // n <= max_seq (check_decode)
+    kv->s_temp = temperature; kv->s_topk = top_k;
+    for (int i = 0; i < n; ++i) PGV_TRY(decode_step(ctx, m, kv, eos_id, AM_INC_POS | AM_RECORD | AM_SAMPLE, s));
+    PGV_HIP(hipMemcpy2DAsync(d_tokens, (size_t)n * 4, kv->d_hist, (size_t)kv->max_seq * 4, (size_t)n * 4, B, hipMemcpyDeviceToDevice, s));
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // mm_projector
 // ---------------------------------------------------------------------------------------------
@@ -512,7 +568,7 @@ extern "C" int pgv_projector(pgv_ctx* ctx, int dtype, int depth, const void* con
     hipStream_t s = (hipStream_t)stream;
     void* tmp[2] = {nullptr, nullptr};
     if (depth > 1) {
-        PGV_TRY(pgv_ws_reserve(ctx, 2 * pgv_align((size_t)rows * hidden * 2)));
+        PGV_TRY(pgv_ws_reserve(ctx, 2 * pgv_align((size_t)rows * hidden * 2), s));
         tmp[0] = pgv_ws_alloc(ctx, (size_t)rows * hidden * 2);
         tmp[1] = pgv_ws_alloc(ctx, (size_t)rows * hidden * 2);
     }

@@ -57,11 +57,16 @@ struct pgv_ctx {
     bool prof = false;
     pgv_prof_family fam[PGV_NFAMILY];
     hipStream_t cap_stream = nullptr;   // used only to capture decode graphs
+    hipStream_t ws_stream = nullptr;    // stream of the last call that carved the arena (the arena is stream-ordered: one stream at a time)
+    bool ws_stream_valid = false;
+    hipEvent_t ws_event = nullptr;
     float* zero_bias = nullptr;         // PGV_ZERO_BIAS_LEN zeros: stands in for a null bias so the persistent GEMM epilogue is branch-free
 };
 
-// Reserve the arena for a call (may hipMalloc: never call inside graph capture).
-int pgv_ws_reserve(pgv_ctx* ctx, size_t bytes);
+// Reserve the arena for a call enqueued on `s` (may hipMalloc: never call inside graph capture).  The arena is reused by every call, so
+// the only ordering between two users is stream order: when `s` differs from the stream of the previous user, `s` is made to wait for
+// everything that stream had queued (one event), which keeps two torch streams on one context correct (if serialised).
+int pgv_ws_reserve(pgv_ctx* ctx, size_t bytes, hipStream_t s);
 // Bump allocate (256-B aligned) from the reserved arena; nullptr if exhausted.
 void* pgv_ws_alloc(pgv_ctx* ctx, size_t bytes);
 inline void pgv_ws_reset(pgv_ctx* ctx) { ctx->ws_off = 0; }

@@ -83,7 +83,7 @@ extern "C" void pgv_vit_destroy(pgv_vit* vit) {
 
 extern "C" int pgv_vit_missing(const pgv_vit* vit) { return vit ? vit->expected - (int)vit->loaded.size() : -1; }
 
-extern "C" int pgv_vit_load_tensor(pgv_vit* v, const char* name_in, const void* data, int src_dtype, int on_device, void* stream) {
+extern "C" int pgv_vit_load_tensor(pgv_vit* v, const char* name_in, const void* data, int src_dtype, int on_device, int64_t numel, void* stream) {
     PGV_CHECK(v && name_in && data, "pgv_vit_load_tensor: null argument");
     std::string name(name_in);
     if (name.rfind("vision_model.", 0) == 0) name = name.substr(13);
@@ -125,6 +125,8 @@ extern "C" int pgv_vit_load_tensor(pgv_vit* v, const char* name_in, const void* 
         else { pgv_set_error("pgv_vit_load_tensor: unexpected key '%s'", name_in); return PGV_ENAME; }
     } else { pgv_set_error("pgv_vit_load_tensor: unexpected key '%s'", name_in); return PGV_ENAME; }
     if (d.dst_stride == 0) d.dst_stride = d.cols;
+    PGV_CHECK(numel == d.rows * d.cols, "pgv_vit_load_tensor: size mismatch for '%s': %lld elements given, the model expects %lld x %lld", name_in,
+              (long long)numel, d.rows, d.cols);
     PGV_TRY(pgv_pack_tensor(d, data, src_dtype, on_device, (hipStream_t)stream));
     if (counted) v->loaded.insert(name);
     return PGV_OK;
@@ -141,7 +143,7 @@ extern "C" int pgv_vit_forward(pgv_ctx* ctx, pgv_vit* v, const void* d_pixels, i
     const size_t Mmax = (size_t)Tc_max * N;
     const size_t b_resid = pgv_align(Mmax * C * 4), b_xn = pgv_align(Mmax * C * 2), b_qkv = pgv_align(Mmax * 3 * C * 2), b_ao = pgv_align(Mmax * C * 2),
                  b_h = pgv_align(Mmax * I * 2 > (size_t)Tc_max * P * ((size_t)v->Kp * 2 + C * 4) + 512 ? Mmax * I * 2 : (size_t)Tc_max * P * ((size_t)v->Kp * 2 + C * 4) + 512);
-    PGV_TRY(pgv_ws_reserve(ctx, b_resid + b_xn + b_qkv + b_ao + b_h));
+    PGV_TRY(pgv_ws_reserve(ctx, b_resid + b_xn + b_qkv + b_ao + b_h, s));
     float* resid = (float*)pgv_ws_alloc(ctx, b_resid);
     char* xn = (char*)pgv_ws_alloc(ctx, b_xn);
     char* qkv = (char*)pgv_ws_alloc(ctx, b_qkv);

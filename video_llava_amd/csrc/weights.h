@@ -27,4 +27,7 @@ inline __host__ __device__ long long pgv_blocked_offset(long long row, long long
 // Enqueue the conversion on `s`.  Host sources are staged through a temporary device buffer (synchronous).
 int pgv_pack_tensor(const PackDst& d, const void* data, int src_dtype, int on_device, hipStream_t s);
 
+// Zero rows [row0, row0 + nrows) of a 16-bit matrix in the blocked layout (all-zero bits are +0 in fp16 and bf16).
+int pgv_zero_rows_blocked(void* blocked16, long long row0, long long nrows, long long cols, hipStream_t s);
+
 inline size_t pgv_dtype_size(int dt) { return dt == PGV_F32 ? 4 : 2; }

@@ -45,7 +45,24 @@ int launch_pack(const PackDst& d, const void* src, hipStream_t s) {
     return PGV_OK;
 }
 
+__global__ __launch_bounds__(256) void zero_rows_blocked_kernel(uint16_t* __restrict__ dst, long long row0, long long nrows, long long cols) {
+    const long long total = nrows * cols;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / cols, c = i - r * cols;
+        dst[pgv_blocked_offset(row0 + r, c, cols)] = 0;
+    }
+}
+
 }  // namespace
+
+int pgv_zero_rows_blocked(void* blocked16, long long row0, long long nrows, long long cols, hipStream_t s) {
+    if (nrows <= 0) return PGV_OK;
+    const long long total = nrows * cols;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(zero_rows_blocked_kernel, dim3(grid), dim3(256), 0, s, (uint16_t*)blocked16, row0, nrows, cols);
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
 
 int pgv_pack_tensor(const PackDst& d, const void* data, int src_dtype, int on_device, hipStream_t s) {
     PGV_CHECK(data != nullptr && d.ptr != nullptr && d.rows > 0 && d.cols > 0, "pack: bad arguments");

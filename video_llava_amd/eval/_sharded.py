@@ -14,9 +14,13 @@ from __future__ import annotations
 import torch
 
 
+MAX_BATCH = 16      # pgv_kv_create: the decode GEMVs put the batch on the 16 columns of one MFMA tile
+
+
 def add_runtime_arguments(parser):
     """Flags this package adds to every runner on top of the reference's."""
-    parser.add_argument("--batch", type=int, default=8, help="clips answered together per GPU (greedy decoding)")
+    parser.add_argument("--batch", type=int, default=8, choices=range(1, MAX_BATCH + 1), metavar=f"[1-{MAX_BATCH}]",
+                        help=f"clips answered together per GPU (greedy decoding; the decode kernels tile at most {MAX_BATCH} sequences)")
     parser.add_argument("--max_new_tokens", type=int, default=1024)
     parser.add_argument("--do_sample", action="store_true", help="reference decoding: temperature-0.2 sampling, one clip at a time")
     return parser
@@ -46,7 +50,8 @@ def answer_tasks(args, tasks, components, load_frames, rank, world):
     stop_strs = {}
 
     def infer_batch(indices):
-        """-> (tokens [n, <= max_new] int32, lengths); a task that cannot be loaded gets length 0."""
+        """-> (tokens [n, <= max_new] int32, lengths).  Length encoding: 0 = the task failed (no prediction), k + 1 = an answer of k tokens
+        (k = 0 is a legitimate empty answer: the reference writes pred = '' when the first token is EOS)."""
         prompts, feats, keep = [], [], []
         last_path, last_feat = None, None
         for j, idx in enumerate(indices):
@@ -58,26 +63,42 @@ def answer_tasks(args, tasks, components, load_frames, rank, world):
                 if t["path"] != last_path:                             # consecutive questions on one clip share its features
                     last_feat = video_features(load_frames(t["path"]), vision_tower, image_processor)
                     last_path = t["path"]
-                feats.append(last_feat)
                 prompt, stop = build_prompt(t["question"], args.conv_mode, video_token_len, use_se)
+                ids = tokenizer([prompt]).input_ids[0]
+                feats.append(last_feat)
                 stop_strs[idx] = stop
-                prompts.append(tokenizer([prompt]).input_ids[0])
+                prompts.append(ids)
                 keep.append(j)
             except Exception as e:                                     # noqa: BLE001 -- the reference's print-and-continue
                 print(f"Error processing video file '{t['name']}': {e}")
         toks = torch.zeros(len(indices), args.max_new_tokens, dtype=torch.int32)
         lens = [0] * len(indices)
+        eos = model.config.eos_token_id
+
+        def record(j, row, n_prompt):
+            new = row[n_prompt:].tolist()
+            if eos is not None and eos in new:
+                new = new[:new.index(eos)]
+            new = new[:args.max_new_tokens]
+            toks[j, :len(new)] = torch.tensor(new, dtype=torch.int32)
+            lens[j] = len(new) + 1
+
         if keep:
-            out = model.generate(prompts, video_spatio_temporal_features=torch.stack(feats), do_sample=False,
-                                 max_new_tokens=args.max_new_tokens).cpu()
-            eos = model.config.eos_token_id
-            for r, j in enumerate(keep):
-                new = out[r, len(prompts[r]):].tolist()
-                if eos is not None and eos in new:
-                    new = new[:new.index(eos)]
-                new = new[:args.max_new_tokens]
-                toks[j, :len(new)] = torch.tensor(new, dtype=torch.int32)
-                lens[j] = max(len(new), 1) if new else 0
+            try:
+                out = model.generate(prompts, video_spatio_temporal_features=torch.stack(feats), do_sample=False,
+                                     max_new_tokens=args.max_new_tokens).cpu()
+                for r, j in enumerate(keep):
+                    record(j, out[r], len(prompts[r]))
+            except Exception as e:                                     # noqa: BLE001
+                # one bad sample (e.g. an over-long prompt) must not take the whole group down: the reference loses only that sample
+                print(f"batched generation failed ({e}); retrying the {len(keep)} samples one by one")
+                for r, j in enumerate(keep):
+                    try:
+                        out = model.generate([prompts[r]], video_spatio_temporal_features=feats[r][None], do_sample=False,
+                                             max_new_tokens=args.max_new_tokens).cpu()
+                        record(j, out[0], len(prompts[r]))
+                    except Exception as e1:                            # noqa: BLE001
+                        print(f"Error processing video file '{tasks[indices[j]]['name']}': {e1}")
         return toks, lens
 
     if args.do_sample:
@@ -98,14 +119,21 @@ def answer_tasks(args, tasks, components, load_frames, rank, world):
         return preds
 
     device = vision_tower.device if hasattr(vision_tower, "device") else torch.device("cpu")
-    answers = parallel.run_sharded(len(tasks), infer_batch, args.max_new_tokens, rank, world, device, per_gpu_batch=args.batch)
+    answers = parallel.run_sharded(len(tasks), infer_batch, args.max_new_tokens, rank, world, device, per_gpu_batch=args.batch,
+                                   length_offset=1)
+    from ..model.utils import first_stop_length
     preds = []
     for idx, ids in enumerate(answers):
-        if not ids:
-            preds.append(None)
+        if ids is None:
+            preds.append(None)                                         # failed / missing: left out of the output like the reference's except
             continue
-        text = tokenizer.batch_decode([ids], skip_special_tokens=True)[0].strip()
         stop = stop_strs.get(idx) or build_prompt("", args.conv_mode, 1, use_se)[1]
+        # The batched greedy loop runs to EOS / max_new_tokens; the reference's per-sample loop additionally stops when the conv mode's stop
+        # string shows up in the decoded tail (KeywordsStoppingCriteria).  Cut where that loop would have stopped, then clean like it does.
+        n = first_stop_length(ids, tokenizer, [stop]) if stop else None
+        if n is not None:
+            ids = ids[:n]
+        text = tokenizer.batch_decode([ids], skip_special_tokens=True)[0].strip()
         preds.append(text.rstrip(stop).strip() if stop else text)     # the reference's own stop handling (inference.py:123)
     return preds
 

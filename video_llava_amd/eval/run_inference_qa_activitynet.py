@@ -63,7 +63,7 @@ def run_inference(args, components=None, load_frames=None):
     rank, world, components = _sharded.setup(args, components)
     image_processor = components[3]
     frame_size = (image_processor.crop_size["height"], image_processor.crop_size["width"])
-    load_frames = load_frames or (lambda path: load_video(path, shape=frame_size))
+    load_frames = load_frames or (lambda path: load_video(path, shape=frame_size, device_resize=True))
     samples = load_samples(args.gt_file_question, args.gt_file_answers)
     os.makedirs(args.output_dir, exist_ok=True)
     tasks = [{"path": find_video(args.video_dir, s["video_name"]), "name": s["video_name"], "question": s["question"]} for s in samples]

@@ -31,7 +31,7 @@ def run_inference(args, components=None, load_frames=None, video_stem=None, exte
     rank, world, components = _sharded.setup(args, components)
     image_processor = components[3]
     frame_size = (image_processor.crop_size["height"], image_processor.crop_size["width"])
-    load_frames = load_frames or (lambda path: load_video(path, shape=frame_size))
+    load_frames = load_frames or (lambda path: load_video(path, shape=frame_size, device_resize=True))
     video_stem = video_stem or (lambda sample: f"video{sample['video_id']}")
     os.makedirs(args.output_dir, exist_ok=True)
     with open(args.gt_file) as f:

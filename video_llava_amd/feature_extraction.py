@@ -28,32 +28,61 @@ LLAVA_VERSIONS = {"1.1": ("openai/clip-vit-large-patch14", (224, 224)), "1.5": (
 VIDEO_EXTENSIONS_NPY = (".npy",)
 
 
-def load_video(vis_path, num_frm=100, shape=(224, 224)):
-    """Up to `num_frm` uniformly sampled frames as a uint8 array [k, h, w, 3]: nearest-neighbour resize to `shape` without aspect
-    preservation, exactly the arithmetic of the reference (:13-32; F.interpolate default mode on the float tensor, cast back to
-    uint8).  The reference returns PIL images only to feed CLIPImageProcessor; the HIP preprocessing takes the array directly."""
+class NativeFrames:
+    """Sampled frames at the decoder's resolution (uint8 [k, H, W, 3]) plus the size `load_video` would resize them to.  The resize is
+    then done on the device, fused with the CLIP normalisation (pgv_ingest_u8: the same nearest-neighbour index rule, bit-exact), so
+    the host never touches the pixels and the upload is the native uint8 frames."""
+    __slots__ = ("array", "shape")
+
+    def __init__(self, array: np.ndarray, shape):
+        self.array, self.shape = array, (int(shape[0]), int(shape[1]))
+
+    def __len__(self):
+        return self.array.shape[0]
+
+    def resized(self) -> np.ndarray:
+        """Host twin of the device resize: exactly the reference's statements (eval/model_utils.py:38-43)."""
+        return resize_nearest(self.array, self.shape)
+
+
+def resize_nearest(arr: np.ndarray, shape) -> np.ndarray:
+    h, w = shape
+    if arr.shape[-3] == h and arr.shape[-2] == w:
+        return arr
+    t = torch.from_numpy(np.ascontiguousarray(arr)).permute(0, 3, 1, 2).float()
+    t = torch.nn.functional.interpolate(t, size=(h, w))
+    return t.permute(0, 2, 3, 1).to(torch.uint8).numpy()
+
+
+def sample_frames(vis_path, num_frm=100) -> np.ndarray:
+    """Up to `num_frm` uniformly sampled frames (get_seq_frames) at the file's own resolution, uint8 [k, H, W, 3]."""
     if str(vis_path).endswith(VIDEO_EXTENSIONS_NPY):
         src = np.load(vis_path, mmap_mode="r")
         if src.dtype != np.uint8 or src.ndim != 4 or src.shape[-1] != 3:
             raise ValueError(f"{vis_path}: expected uint8 [T, H, W, 3], got {src.dtype} {src.shape}")
         total = src.shape[0]
         k = min(total, num_frm)
-        arr = np.ascontiguousarray(src[get_seq_frames(total, k)])
-    else:
-        try:
-            from decord import VideoReader, cpu
-        except ImportError as e:
-            raise RuntimeError("load_video needs the `decord` package to decode video files (or pass .npy frame arrays)") from e
-        vr = VideoReader(vis_path, ctx=cpu(0))
-        total = len(vr)
-        k = min(total, num_frm)
-        arr = vr.get_batch(get_seq_frames(total, k)).asnumpy()
-    h, w = shape
-    if arr.shape[-3] != h or arr.shape[-2] != w:
-        t = torch.from_numpy(arr).permute(0, 3, 1, 2).float()
-        t = torch.nn.functional.interpolate(t, size=(h, w))
-        arr = t.permute(0, 2, 3, 1).to(torch.uint8).numpy()
-    return arr
+        return np.ascontiguousarray(src[get_seq_frames(total, k)])
+    try:
+        from decord import VideoReader, cpu
+    except ImportError as e:
+        raise RuntimeError("load_video needs the `decord` package to decode video files (or pass .npy frame arrays)") from e
+    vr = VideoReader(vis_path, ctx=cpu(0))
+    total = len(vr)
+    k = min(total, num_frm)
+    return vr.get_batch(get_seq_frames(total, k)).asnumpy()
+
+
+def load_video(vis_path, num_frm=100, shape=(224, 224), device_resize=False):
+    """Up to `num_frm` uniformly sampled frames as a uint8 array [k, h, w, 3]: nearest-neighbour resize to `shape` without aspect
+    preservation, exactly the arithmetic of the reference (:13-32; F.interpolate default mode on the float tensor, cast back to
+    uint8).  The reference returns PIL images only to feed CLIPImageProcessor; the HIP preprocessing takes the array directly.
+    device_resize=True returns the frames un-resized as `NativeFrames`: inference.frames_to_pixels then resizes and normalises them
+    in one HIP pass (pgv_ingest_u8)."""
+    arr = sample_frames(vis_path, num_frm)
+    if device_resize:
+        return NativeFrames(arr, shape)
+    return resize_nearest(arr, shape)
 
 
 def get_spatio_temporal_features(features, num_temporal_tokens=100):
@@ -87,9 +116,11 @@ def parse_args(argv=None):
 def extract_clip_features(video_path, vision_tower, frame_size):
     """One video -> np.float16 [100 + P, 1024] (the body of the reference's per-video try block, :103-123)."""
     from . import _lib
-    frames = load_video(video_path, shape=frame_size)
+    frames = sample_frames(video_path)                      # native resolution: resize + normalise happen in one pass on the device
     dev = vision_tower.device
-    px = _lib.Context.get(dev).preprocess_u8(torch.from_numpy(frames).to(dev), vision_tower.dtype)
+    if frame_size[0] != frame_size[1]:
+        raise ValueError(f"square CLIP inputs only (got {frame_size})")
+    px = _lib.Context.get(dev).ingest_u8(torch.from_numpy(frames).to(dev), frame_size[0], vision_tower.dtype)
     with torch.no_grad():
         hidden = vision_tower(px, output_hidden_states=True).hidden_states[-2]
     return get_spatio_temporal_features(hidden[:, 1:])

@@ -49,6 +49,14 @@ def frames_to_pixels(video_frames, image_processor, vision_tower) -> torch.Tenso
     HIP path (pgv_preprocess_u8 == CLIPImageProcessor for crop-sized frames); anything else goes through
     the caller's image_processor exactly like the reference (inference.py:86-89)."""
     S = vision_tower.config.image_size
+    from .feature_extraction import NativeFrames
+    if isinstance(video_frames, NativeFrames):
+        # frames at the decoder's resolution: load_video's nearest resize + CLIPImageProcessor in one HIP pass (pgv_ingest_u8)
+        if video_frames.shape == (S, S):
+            dev = vision_tower.device
+            return _lib.Context.get(dev).ingest_u8(torch.from_numpy(video_frames.array).to(dev), S, vision_tower.dtype)
+        video_frames = video_frames.resized()                # not the tower's crop size: host resize, then the caller's image_processor
+        video_frames = [video_frames[i] for i in range(video_frames.shape[0])]
     if isinstance(video_frames, np.ndarray) and video_frames.dtype == np.uint8 and video_frames.shape[1:] == (S, S, 3):
         dev = vision_tower.device
         return _lib.Context.get(dev).preprocess_u8(torch.from_numpy(video_frames).to(dev), vision_tower.dtype)

@@ -23,3 +23,32 @@ class KeywordsStoppingCriteria:
             return True
         text = self.tokenizer.batch_decode(output_ids[:, self.start_len:], skip_special_tokens=True)[0]
         return any(k in text for k in self.keywords)
+
+
+def first_stop_length(new_tokens, tokenizer, keywords):
+    """Number of generated tokens a per-token loop with `KeywordsStoppingCriteria(keywords, ...)` keeps, or None when it never fires.
+    The criterion's first call (one generated token) only records the start; from the second token on it fires when the last id is a
+    single-id keyword or the decoded tail contains a keyword -- so this is the smallest n >= 2 with either property.  `keyword in
+    decode(tokens[:n])` is monotone in n for text keywords, hence a binary search instead of the reference's decode-per-token."""
+    ids = [tokenizer(k).input_ids for k in keywords]
+    keyword_ids = {i[0] for i in ids if isinstance(i, list) and len(i) == 1}
+    toks = [int(t) for t in new_tokens]
+    n_id = next((i + 1 for i in range(1, len(toks)) if toks[i] in keyword_ids), None)
+
+    def has(n):
+        text = tokenizer.batch_decode([toks[:n]], skip_special_tokens=True)[0]
+        return any(k in text for k in keywords)
+
+    n_txt = None
+    if len(toks) >= 2 and has(len(toks)):
+        lo, hi = 2, len(toks)                       # invariant: has(hi)
+        while lo < hi:
+            mid = (lo + hi) // 2
+            if has(mid):
+                hi = mid
+            else:
+                lo = mid + 1
+        n_txt = hi
+    if n_id is None:
+        return n_txt
+    return n_id if n_txt is None else min(n_id, n_txt)

@@ -162,15 +162,36 @@ class VideoChatGPTLlamaForCausalLM(nn.Module):
         return out
 
     def resize_token_embeddings(self, new_num_tokens: int):
-        """eval/model_utils.py:119: grow embed_tokens / lm_head for the three video tokens."""
+        """eval/model_utils.py:119: grow embed_tokens / lm_head for the three video tokens (new rows are zero until a checkpoint fills
+        them; HF initialises them from the old rows' statistics -- neither is ever a trained value)."""
         _lib.check(self.ctx.lib.pgv_llm_resize_vocab(self.handle, int(new_num_tokens), _lib.stream_ptr(self.device_)),
                    "resize_token_embeddings")
         self.config.vocab_size = int(new_num_tokens)
+        for kv in self._kv.values():                    # logits buffers / captured decode graphs carry the old vocabulary size
+            self.ctx.lib.pgv_kv_destroy(kv)
+        self._kv.clear()
 
     # ---- weights ----------------------------------------------------------------------------------------
+    def _expected_shape(self, key: str):
+        """Shape HF's LlamaForCausalLM holds under `key` for this config and the CURRENT vocabulary (None: not a decoder key)."""
+        c = self.config
+        H, I, V = c.hidden_size, c.intermediate_size, self.vocab_size
+        if key in ("model.embed_tokens.weight", "lm_head.weight"):
+            return (V, H)
+        if key == "model.norm.weight":
+            return (H,)
+        if not key.startswith("model.layers."):
+            return None
+        rest = key.split(".", 3)[-1]
+        return {"self_attn.q_proj.weight": (H, H), "self_attn.k_proj.weight": (H, H), "self_attn.v_proj.weight": (H, H),
+                "self_attn.o_proj.weight": (H, H), "mlp.gate_proj.weight": (I, H), "mlp.up_proj.weight": (I, H),
+                "mlp.down_proj.weight": (H, I), "input_layernorm.weight": (H,), "post_attention_layernorm.weight": (H,)}.get(rest)
+
     def load_state_dict(self, sd: dict, strict: bool = True):
         """Routes `model.mm_projector.*` to the projector module and every other key to the packed device weights.
-        Returns an object with `.missing_keys` / `.unexpected_keys` like torch (eval/model_utils.py:124-126)."""
+        Returns an object with `.missing_keys` / `.unexpected_keys` like torch (eval/model_utils.py:124-126); a tensor whose shape
+        disagrees with the config (or, for the vocabulary matrices, with the current vocabulary size) raises torch's "size mismatch"
+        RuntimeError -- also under strict=False, as torch does."""
         lib = self.ctx.lib
         unexpected: List[str] = []
         proj_sd = {}
@@ -186,15 +207,18 @@ class VideoChatGPTLlamaForCausalLM(nn.Module):
             if v.dtype not in (torch.float32, torch.float16, torch.bfloat16):
                 v = v.float()
             v = v.contiguous()
+            exp = self._expected_shape(k)
+            if exp is not None and tuple(v.shape) != exp:
+                raise RuntimeError(f"Error(s) in loading state_dict for VideoChatGPTLlamaForCausalLM:\n\tsize mismatch for {k}: copying a param "
+                                   f"with shape {tuple(v.shape)} from checkpoint, the shape in current model is {exp}.")
             if v.is_cuda:
                 torch.cuda.current_stream(v.device).synchronize()
             dev = 1 if v.is_cuda else 0
             if k in ("model.embed_tokens.weight", "lm_head.weight"):
-                rows = min(v.shape[0], self.vocab_size)      # a checkpoint with a smaller vocabulary fills the first rows
-                rc = lib.pgv_llm_load_rows(self.handle, k.encode(), v.data_ptr(), _lib.dtype_code(v.dtype), dev, 0, rows,
+                rc = lib.pgv_llm_load_rows(self.handle, k.encode(), v.data_ptr(), _lib.dtype_code(v.dtype), dev, 0, v.shape[0], v.numel(),
                                            _lib.stream_ptr(self.device_))
             else:
-                rc = lib.pgv_llm_load_tensor(self.handle, k.encode(), v.data_ptr(), _lib.dtype_code(v.dtype), dev,
+                rc = lib.pgv_llm_load_tensor(self.handle, k.encode(), v.data_ptr(), _lib.dtype_code(v.dtype), dev, v.numel(),
                                              _lib.stream_ptr(self.device_))
             if rc == _lib.PGV_ENAME:
                 unexpected.append(k)
@@ -323,16 +347,41 @@ class VideoChatGPTLlamaForCausalLM(nn.Module):
                                                       _lib.stream_ptr(self.device_)), "pgv_llm_decode_greedy")
         return toks
 
+    def sample_last(self, kv, u: torch.Tensor, temperature: float, top_k: int = 50) -> torch.Tensor:
+        """Draw the next token of every sequence from the logits of the last prefill / decode call (pgv_llm_sample): u [B] uniforms."""
+        u = u.to(device=self.device_, dtype=torch.float32).contiguous()
+        nxt = torch.empty(u.numel(), dtype=torch.int32, device=self.device_)
+        _lib.check(self.ctx.lib.pgv_llm_sample(self.ctx.handle, self.handle, kv, float(temperature), int(top_k), u.data_ptr(), nxt.data_ptr(),
+                                               _lib.stream_ptr(self.device_)), "pgv_llm_sample")
+        return nxt
+
+    def decode_sample(self, kv, first: torch.Tensor, n: int, eos_id: int, temperature: float, top_k: int, u: torch.Tensor) -> torch.Tensor:
+        """n sampled steps on the device (pgv_llm_decode_sample): u [n, B] uniforms, step i draws with u[i]."""
+        B = first.shape[0]
+        u = u.to(device=self.device_, dtype=torch.float32).contiguous()
+        assert u.shape == (n, B)
+        toks = torch.empty(B, n, dtype=torch.int32, device=self.device_)
+        _lib.check(self.ctx.lib.pgv_llm_decode_sample(self.ctx.handle, self.handle, kv, first.data_ptr(), n, eos_id, float(temperature), int(top_k),
+                                                      u.data_ptr(), toks.data_ptr(), _lib.stream_ptr(self.device_)), "pgv_llm_decode_sample")
+        return toks
+
     # ---- generate ---------------------------------------------------------------------------------------
     @torch.no_grad()
     def generate(self, input_ids, video_spatio_temporal_features: Optional[torch.Tensor] = None, do_sample: bool = False,
                  temperature: float = 1.0, max_new_tokens: int = 1024, stopping_criteria=None, eos_token_id="config",
-                 chunk: int = 32, generator: Optional[torch.Generator] = None, **_unused):
+                 chunk: int = 32, generator: Optional[torch.Generator] = None, top_k: int = 50, **_unused):
         """Returns LongTensor [B, S + n_new] on the device, prompt echoed (checked by inference.py:115-117).
 
         input_ids: LongTensor [B, S] (equal-length prompts, the reference's case) or a list of id lists (ragged batch).
-        Greedy without stopping criteria runs `chunk` steps per host round trip; sampling (the reference's default
-        temperature-0.2 multinomial, inference.py:109-110) and stopping criteria need the token on the host each step."""
+        Tokens never leave the device inside a chunk of `chunk` steps, in both modes:
+          * greedy: pgv_llm_decode_greedy;
+          * do_sample=True (the reference's default, temperature 0.2, inference.py:109-110): HF's sample loop is logits / temperature ->
+            top-k mask (top_k = 50 is HF's default GenerationConfig value, which the reference inherits) -> softmax -> multinomial.  The
+            multinomial draw is an inverse-CDF pick in a HIP kernel (pgv_llm_decode_sample) fed with uniforms drawn up front from
+            `generator` (a device torch.Generator; one uniform per sequence and step, so a run is reproducible from the seed and
+            independent of the chunk size).
+        Stopping criteria (B == 1, as in the reference) are evaluated on the host after each chunk, token by token in generation
+        order, and the output is cut at the first hit: the same ids as a per-token loop, the surplus steps of the chunk are discarded."""
         if torch.is_tensor(input_ids):
             seqs = [row.tolist() for row in input_ids.cpu()]
         else:
@@ -345,22 +394,24 @@ class VideoChatGPTLlamaForCausalLM(nn.Module):
             raise ValueError(f"prompt + max_new_tokens = {max_seq} exceeds max_position_embeddings {self.config.max_position_embeddings}")
         max_seq = (max_seq + 63) // 64 * 64
         criteria = list(stopping_criteria) if stopping_criteria else []
-        stepwise = bool(criteria) or do_sample
+        if criteria and B != 1:
+            raise ValueError("stopping_criteria are evaluated on one sequence (the reference passes them with batch size 1 only)")
+        if do_sample and not float(temperature) > 0.0:
+            raise ValueError(f"`temperature` (={temperature}) has to be a strictly positive float; use do_sample=False for greedy decoding")
+        if criteria:
+            chunk = min(chunk, 16)                         # at most 15 surplus steps past a stop string
 
-        def pick(logits):
-            if not do_sample:
-                return logits.argmax(-1).to(torch.int32)
-            probs = torch.softmax(logits / max(float(temperature), 1e-6), dim=-1)
-            return torch.multinomial(probs, 1, generator=generator).squeeze(1).to(torch.int32)
-
-        kv, nxt, logits = self.prefill(seqs, video_spatio_temporal_features, max_seq, want_logits=do_sample)
-        if do_sample:
-            nxt = pick(logits)
+        kv, nxt, _ = self.prefill(seqs, video_spatio_temporal_features, max_seq)
+        u = None
+        if do_sample and max_new_tokens >= 1:
+            u = torch.rand(max_new_tokens, B, device=self.device_, dtype=torch.float32, generator=generator)
+            nxt = self.sample_last(kv, u[0], temperature, top_k)
         new = [[] for _ in range(B)]
         done = [False] * B
         prompt_t = [torch.tensor(s, dtype=torch.long) for s in seqs]
 
         def absorb(tok_host) -> bool:
+            """Append one step's tokens; True = generation is over (HF: EOS on every sequence, or a criterion fires on the new ids)."""
             for b in range(B):
                 if not done[b]:
                     new[b].append(int(tok_host[b]))
@@ -368,35 +419,28 @@ class VideoChatGPTLlamaForCausalLM(nn.Module):
                         done[b] = True
             if all(done):
                 return True
-            if criteria and B == 1:
+            if criteria:
                 cur = torch.cat([prompt_t[0], torch.tensor(new[0], dtype=torch.long)])[None]
                 if any(c(cur, None) for c in criteria):
                     return True
             return False
 
         if max_new_tokens >= 1:
-            if criteria and B == 1:                       # HF calls the criteria once before the first new token is appended
-                for c in criteria:
-                    c(prompt_t[0][None], None)
             stop = absorb(nxt.cpu())
             n_gen = 1
             while not stop and n_gen < max_new_tokens:
-                if stepwise:
-                    nxt, logits = self.decode_step(kv, nxt, want_logits=do_sample)
-                    if do_sample:
-                        nxt = pick(logits)
-                    stop = absorb(nxt.cpu())
-                    n_gen += 1
+                n = min(chunk, max_new_tokens - n_gen)
+                if do_sample:
+                    toks = self.decode_sample(kv, nxt, n, eos_i, temperature, top_k, u[n_gen:n_gen + n])
                 else:
-                    n = min(chunk, max_new_tokens - n_gen)
                     toks = self.decode_greedy(kv, nxt, n, eos_i)
-                    host = toks.cpu()
-                    for i in range(n):
-                        stop = absorb(host[:, i])
-                        n_gen += 1
-                        if stop:
-                            break
-                    nxt = toks[:, n - 1].contiguous()
+                host = toks.cpu()
+                for i in range(n):
+                    stop = absorb(host[:, i])
+                    n_gen += 1
+                    if stop:
+                        break
+                nxt = toks[:, n - 1].contiguous()
         width = max(len(s) + len(n_) for s, n_ in zip(seqs, new))
         pad = eos_i if eos_i >= 0 else 0
         out = torch.full((B, width), pad, dtype=torch.long)

@@ -45,9 +45,11 @@ def shard_capacity(n_items: int, world: int) -> int:
     return (n_items + world - 1) // world
 
 
-def gather_answers(tokens: torch.Tensor, lengths: torch.Tensor, n_items: int, rank: int, world: int):
+def gather_answers(tokens: torch.Tensor, lengths: torch.Tensor, n_items: int, rank: int, world: int, length_offset: int = 0):
     """Collate per-rank answers.  tokens [cap, max_new] int32 and lengths [cap] int32 (cap = shard_capacity; unused slots
     have length -1) -> list of n_items token-id lists in global clip order, identical on every rank.
+    length_offset = 1: lengths carry (answer length + 1) and 0 marks a failed clip, which comes back as None -- an empty answer
+    (first token EOS) is then distinguishable from a failure.
     world == 1 short-circuits without touching torch.distributed."""
     cap, width = tokens.shape
     assert cap == shard_capacity(n_items, world) and lengths.shape == (cap,)
@@ -65,15 +67,16 @@ def gather_answers(tokens: torch.Tensor, lengths: torch.Tensor, n_items: int, ra
         toks = out[r, : cap * width].view(cap, width)
         lens = out[r, cap * width:]
         for slot, idx in enumerate(shard_indices(n_items, r, world)):
-            n = int(lens[slot])
-            answers[idx] = toks[slot, :max(n, 0)].tolist()
+            n = int(lens[slot]) - length_offset
+            answers[idx] = None if (length_offset and n < 0) else toks[slot, :max(n, 0)].tolist()
     return answers
 
 
 def run_sharded(n_items: int, infer_batch: Callable[[Sequence[int]], tuple], max_new_tokens: int, rank: int, world: int,
-                device, per_gpu_batch: int = 8):
+                device, per_gpu_batch: int = 8, length_offset: int = 0):
     """Run `infer_batch(indices) -> (tokens [len(indices), <=max_new] int tensor, lengths list)` over this rank's shard in
-    groups of `per_gpu_batch`, then collate.  A group that raises keeps its slots with length 0."""
+    groups of `per_gpu_batch`, then collate.  A group that raises keeps its slots with length 0.  `length_offset`: see gather_answers
+    (the token count stored for slot j is lengths[j] - length_offset)."""
     mine = shard_indices(n_items, rank, world)
     cap = shard_capacity(n_items, world)
     tokens = torch.zeros(cap, max_new_tokens, dtype=torch.int32, device=device)
@@ -83,10 +86,10 @@ def run_sharded(n_items: int, infer_batch: Callable[[Sequence[int]], tuple], max
         try:
             toks, lens = infer_batch(group)
             for j in range(len(group)):
-                n = int(lens[j])
+                n = max(int(lens[j]) - length_offset, 0)
                 tokens[g0 + j, :n] = toks[j, :n].to(device=device, dtype=torch.int32)
-                lengths[g0 + j] = n
+                lengths[g0 + j] = int(lens[j])
         except Exception as e:                               # noqa: BLE001 -- same "print and continue" policy as the reference
             print(f"[rank {rank}] Error processing clips {group}: {e}")
             lengths[g0:g0 + len(group)] = 0
-    return gather_answers(tokens, lengths, n_items, rank, world)
+    return gather_answers(tokens, lengths, n_items, rank, world, length_offset)

@@ -105,9 +105,32 @@ class CLIPVisionTower:
     def num_patches(self) -> int:
         return (self.config.image_size // self.config.patch_size) ** 2
 
+    def _expected_shape(self, key: str):
+        """Shape HF's CLIPVisionModel holds under `key` for this config (None: not a key of the tower)."""
+        c = self.config
+        C_, I, p = c.hidden_size, c.intermediate_size, c.patch_size
+        k = key[len("vision_model."):] if key.startswith("vision_model.") else key
+        fixed = {"embeddings.class_embedding": (C_,), "embeddings.patch_embedding.weight": (C_, 3, p, p),
+                 "embeddings.position_embedding.weight": (self.num_patches + 1, C_), "pre_layrnorm.weight": (C_,), "pre_layrnorm.bias": (C_,),
+                 "post_layernorm.weight": (C_,), "post_layernorm.bias": (C_,)}
+        if k in fixed:
+            return fixed[k]
+        if not k.startswith("encoder.layers."):
+            return None
+        rest = k.split(".", 3)[-1]
+        per_layer = {"mlp.fc1.weight": (I, C_), "mlp.fc1.bias": (I,), "mlp.fc2.weight": (C_, I), "mlp.fc2.bias": (C_,)}
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            per_layer[f"self_attn.{n}.weight"] = (C_, C_)
+            per_layer[f"self_attn.{n}.bias"] = (C_,)
+        for n in ("layer_norm1", "layer_norm2"):
+            per_layer[f"{n}.weight"] = (C_,)
+            per_layer[f"{n}.bias"] = (C_,)
+        return per_layer.get(rest)
+
     def load_state_dict(self, sd: dict, strict: bool = True):
         """Accepts HF CLIPVisionModel keys (with or without the `vision_model.` prefix); values may be torch
-        tensors (any device, fp32/fp16/bf16) or numpy arrays."""
+        tensors (any device, fp32/fp16/bf16) or numpy arrays.  A tensor whose shape disagrees with the config raises
+        torch's "size mismatch" RuntimeError (the C ABI re-checks the element count and never reads past the buffer)."""
         lib = self.ctx.lib
         for k, v in sd.items():
             if isinstance(v, np.ndarray):
@@ -118,10 +141,14 @@ class CLIPVisionTower:
                     continue
                 v = v.float()
             v = v.contiguous()
+            exp = self._expected_shape(k)
+            if exp is not None and tuple(v.shape) != exp:
+                raise RuntimeError(f"Error(s) in loading state_dict for CLIPVisionTower:\n\tsize mismatch for {k}: copying a param with shape "
+                                   f"{tuple(v.shape)} from checkpoint, the shape in current model is {exp}.")
             if v.is_cuda:
                 torch.cuda.current_stream(v.device).synchronize()
             rc = lib.pgv_vit_load_tensor(self.handle, k.encode(), v.data_ptr(), _lib.dtype_code(v.dtype), 1 if v.is_cuda else 0,
-                                         _lib.stream_ptr(self.device))
+                                         v.numel(), _lib.stream_ptr(self.device))
             if rc == _lib.PGV_ENAME and not strict:
                 continue
             _lib.check(rc, f"load {k}")
