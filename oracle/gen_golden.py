@@ -232,7 +232,7 @@ def gen_llama_tiny(meta):
     np.savez_compressed(os.path.join(OUT, "llama_tiny.npz"), head_std=0.08, **out)
 
 
-LOADER_CASE = dict(clip_seed=61, llm_seed=62, head_std=0.08, frame_seed=63, n_frames=7, n_new=12,
+LOADER_CASE = dict(clip_seed=61, llm_seed=193, head_std=0.08, frame_seed=63, n_frames=7, n_new=12,
                    question="what is the person in the video doing?", conv_mode="pg-video-llava")
 
 
@@ -278,6 +278,36 @@ def gen_loader(meta):
                 o = model(input_ids=tok, past_key_values=o.past_key_values, video_spatio_temporal_features=f_t, use_cache=True)
                 tok = o.logits[:, -1].argmax(-1, keepdim=True)
         text = tokenizer.batch_decode([toks], skip_special_tokens=True)[0]
+        # the other splice branch (video_chatgpt/model/video_chatgpt.py:147-167; prompt of inference.py:69-70): no start / end tokens
+        vc.use_vid_start_end = False
+        conv2 = conv_templates[c["conv_mode"]].copy()
+        conv2.append_message(conv2.roles[0], c["question"] + "\n" + "<vid_patch>" * video_token_len)
+        conv2.append_message(conv2.roles[1], None)
+        ids2 = tokenizer([conv2.get_prompt()]).input_ids[0]
+        with torch.no_grad():
+            o = model(input_ids=torch.tensor([ids2]), video_spatio_temporal_features=f_t, use_cache=True)
+            toks2 = []
+            tok = o.logits[:, -1].argmax(-1, keepdim=True)
+            for _ in range(c["n_new"]):
+                toks2.append(int(tok))
+                o = model(input_ids=tok, past_key_values=o.past_key_values, video_spatio_temporal_features=f_t, use_cache=True)
+                tok = o.logits[:, -1].argmax(-1, keepdim=True)
+            bad = list(ids2)
+            bad[bad.index(lcfg.vocab - 3) + 3] = 7                       # break the run: count mismatch
+            try:
+                model(input_ids=torch.tensor([bad]), video_spatio_temporal_features=f_t)
+                err_count = "none"
+            except ValueError as e:
+                err_count = str(e)
+            p0 = ids2.index(lcfg.vocab - 3)
+            bad = list(ids2)
+            bad[p0 + 3], bad[p0 + video_token_len] = bad[p0 + video_token_len], bad[p0 + 3]     # same count, run not consecutive
+            try:
+                model(input_ids=torch.tensor([bad]), video_spatio_temporal_features=f_t)
+                err_consec = "none"
+            except ValueError as e:
+                err_consec = str(e)
+        vc.use_vid_start_end = True
         # oracle (fp32) on the same files' contents: the full-vocabulary weights the tree was written from
         w, cw = info["weights"], info["clip_weights"]
     o_pooled = ovis.spatio_temporal_pool_torch(ovis.clip_select_features(ovis.clip_preprocess(frames), cw, ccfg))
@@ -296,7 +326,15 @@ def gen_loader(meta):
     assert min(margins) > 0.05, margins
     assert otoks == toks, (otoks, toks)
     assert max(toks) < 512
+    otoks2, margins2 = ollm.greedy_generate(w, lcfg, ids2, o_pooled.float(), None, None, PATCH, c["n_new"], return_margins=True)
+    meta["loader_nose_min_margin"] = float(min(margins2))
+    assert min(margins2) > 0.05, margins2
+    assert otoks2 == toks2, (otoks2, toks2)
+    meta["splice_error_nose_count"], meta["splice_error_nose_consecutive"] = err_count, err_consec
+    assert err_count == "The number of video patch tokens should be the same as the number of video patches."
+    assert err_consec == "The video patch tokens should be consecutive."
     np.savez_compressed(os.path.join(OUT, "loader.npz"), ids=np.array(ids, np.int64), tokens=np.array(toks, np.int64),
+                        ids_nose=np.array(ids2, np.int64), tokens_nose=np.array(toks2, np.int64),
                         pooled=pooled.numpy(), prefill_logits=prefill_last[:512].numpy(), **{k: np.array(v) for k, v in c.items()},
                         stop_str=np.array(stop_str), text=np.array(text), prompt=np.array(prompt))
 

@@ -16,6 +16,23 @@ def _t(w: dict, key: str, dtype) -> torch.Tensor:
     return (torch.from_numpy(v) if isinstance(v, np.ndarray) else v).to(dtype)
 
 
+class _WeightCache(dict):
+    """Lazily converted copy of a state dict (see LlamaOracle.__init__)."""
+
+    def __init__(self, src: dict, dtype):
+        super().__init__()
+        self._src, self._dtype = src, dtype
+
+    def __missing__(self, key):
+        v = self._src[key]
+        t = (torch.from_numpy(v) if isinstance(v, np.ndarray) else v).to(self._dtype)
+        self[key] = t
+        return t
+
+    def __contains__(self, key):
+        return key in self._src
+
+
 def rms_norm(x: torch.Tensor, g: torch.Tensor, eps: float) -> torch.Tensor:
     """LlamaRMSNorm.forward (HF:llama/modeling_llama.py:61-67): x * rsqrt(mean(x^2) + eps) * weight."""
     var = x.pow(2).mean(-1, keepdim=True)
@@ -49,6 +66,17 @@ def splice_video_embeddings(input_ids: torch.Tensor, embeds: torch.Tensor, video
     A sample without any <vid_patch> is returned unchanged (:113-118, the dummy term is 0)."""
     if int((input_ids == vid_patch).sum()) == 0:
         return embeds
+    if vid_start is None:
+        # use_vid_start_end = False (video_chatgpt/model/video_chatgpt.py:147-167): the <vid_patch> run itself is replaced; its length
+        # must equal the number of video rows and it must be consecutive, else ValueError with the reference's messages.
+        V = video_feats.shape[0]
+        if int((input_ids == vid_patch).sum()) != V:
+            raise ValueError("The number of video patch tokens should be the same as the number of video patches.")
+        idx = torch.where(input_ids == vid_patch)[0]
+        s0 = int(idx[0])
+        if bool((idx != torch.arange(s0, s0 + V)).any()):
+            raise ValueError("The video patch tokens should be consecutive.")
+        return torch.cat([embeds[:s0], video_feats.to(embeds.dtype), embeds[s0 + V:]], dim=0)
     if int((input_ids == vid_start).sum()) != int((input_ids == vid_end).sum()):
         raise ValueError("The number of video start tokens and video end tokens should be the same.")
     starts = torch.where(input_ids == vid_start)[0]
@@ -67,8 +95,10 @@ class LlamaOracle:
     HF LlamaModel.forward, HF:llama/modeling_llama.py:347-418); `step` == the same forward with
     input_ids.shape[1]==1, which skips the splice (:103)."""
 
-    def __init__(self, w: dict, cfg: LlamaCfg, dtype=torch.float32):
-        self.w, self.cfg, self.dtype = w, cfg, dtype
+    def __init__(self, w: dict, cfg: LlamaCfg, dtype=torch.float32, cache_weights: bool = False):
+        """`w` may hold fp32 numpy arrays or 16-bit torch tensors (full-size checkpoints): every use converts to `dtype`;
+        cache_weights=True keeps the converted copies (7B fp32 = 27 GB) instead of converting per forward."""
+        self.w, self.cfg, self.dtype = (_WeightCache(w, dtype) if cache_weights else w), cfg, dtype
         self.k: list[torch.Tensor] = []
         self.v: list[torch.Tensor] = []
         self.pos = 0
@@ -137,22 +167,48 @@ class LlamaOracle:
 
 def greedy_generate(w: dict, cfg: LlamaCfg, input_ids, video_feats, vid_start: int, vid_end: int, vid_patch: int,
                     max_new_tokens: int, eos_id: int | None = None, dtype=torch.float32,
-                    return_margins: bool = False):
+                    return_margins: bool = False, cache_weights: bool = False, return_logits: bool = False):
     """Greedy decode by driving forward (SURVEY.md 8c oracle recipe; replaces model.generate of
     video_chatgpt/inference.py:105-112 with do_sample=False).  Returns the new token ids (and the
     top-1/top-2 logit gap of each step when `return_margins`)."""
-    m = LlamaOracle(w, cfg, dtype)
+    m = LlamaOracle(w, cfg, dtype, cache_weights=cache_weights)
     logits = m.prefill(input_ids, video_feats, vid_start, vid_end, vid_patch)
-    toks, margins = [], []
-    for _ in range(max_new_tokens):
+    toks, margins, all_logits = [], [], []
+    for i in range(max_new_tokens):
         top2 = torch.topk(logits[0], 2)
         tok = int(top2.indices[0])
         toks.append(tok)
         margins.append(float(top2.values[0] - top2.values[1]))
-        if eos_id is not None and tok == eos_id:
+        if return_logits:
+            all_logits.append(logits[0].clone())
+        if (eos_id is not None and tok == eos_id) or i + 1 == max_new_tokens:
             break
         logits = m.step(tok)
+    if return_logits:
+        return toks, margins, torch.stack(all_logits)
     return (toks, margins) if return_margins else toks
+
+
+def sample_cdf(logits, temperature: float, top_k: int = 50, dtype=torch.float64):
+    """The distribution HF's sample loop draws from, as a CDF over the vocabulary: TemperatureLogitsWarper (scores / temperature,
+    HF:generation/logits_process.py:302), TopKLogitsWarper (`scores < topk(scores, k)[..., -1]` -> -inf, :593; k = 50 is HF's default
+    GenerationConfig value, HF:generation/configuration_utils.py:617, which the reference inherits at video_chatgpt/inference.py:106-112),
+    softmax (HF:generation/utils.py:2921).  Returns cumsum(probs) [B, V] in `dtype`."""
+    x = torch.as_tensor(logits).to(dtype) / temperature
+    if top_k and 0 < top_k < x.shape[-1]:
+        kth = torch.topk(x, top_k, dim=-1).values[..., -1, None]
+        x = x.masked_fill(x < kth, float("-inf"))
+    return torch.cumsum(torch.softmax(x, dim=-1), dim=-1)
+
+
+def sample_pick(logits, u, temperature: float, top_k: int = 50, dtype=torch.float64):
+    """Inverse-CDF draw: the first vocabulary index whose cumulative probability exceeds u (u [B] uniforms in [0, 1)) -- what
+    torch.multinomial(probs, 1) (HF:generation/utils.py:2923) does with its own uniform.  Returns (tokens [B], distance of u to the
+    nearest CDF step [B]): a HIP pick is required to match only where that distance is above summation-order noise."""
+    cdf = sample_cdf(logits, temperature, top_k, dtype)
+    uu = torch.as_tensor(u).to(dtype)[:, None]
+    tok = (cdf <= uu).sum(-1).clamp_max(cdf.shape[-1] - 1)
+    return tok, (cdf - uu).abs().min(-1).values
 
 
 def quantize_e4m3_rows(w) -> "torch.Tensor":

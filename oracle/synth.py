@@ -137,6 +137,60 @@ def make_llama_weights(cfg: LlamaCfg, seed: int = 0, std: float = 0.02,
     return w
 
 
+def llama_tensor_specs(cfg: LlamaCfg, std: float = 0.02, head_std: float | None = None):
+    """[(key, shape, std, offset)] of a VideoChatGPTLlamaForCausalLM state dict in a fixed order (value = offset + N(0, std))."""
+    H, I, V = cfg.hidden, cfg.inter, cfg.vocab
+    hs = std if head_std is None else head_std
+    specs = [("model.embed_tokens.weight", (V, H), hs, 0.0)]
+    for i in range(cfg.layers):
+        q = f"model.layers.{i}."
+        for name in ("q_proj", "k_proj", "v_proj", "o_proj"):
+            specs.append((q + f"self_attn.{name}.weight", (H, H), std, 0.0))
+        specs += [(q + "mlp.gate_proj.weight", (I, H), std, 0.0), (q + "mlp.up_proj.weight", (I, H), std, 0.0),
+                  (q + "mlp.down_proj.weight", (H, I), std, 0.0), (q + "input_layernorm.weight", (H,), 0.1, 1.0),
+                  (q + "post_attention_layernorm.weight", (H,), 0.1, 1.0)]
+    specs += [("model.norm.weight", (H,), 0.1, 1.0), ("lm_head.weight", (V, H), hs, 0.0)]
+    if cfg.projector == "linear":
+        specs += [("model.mm_projector.weight", (H, cfg.mm_hidden), std, 0.0), ("model.mm_projector.bias", (H,), std, 0.0)]
+    elif cfg.projector.startswith("mlp"):
+        depth = int(cfg.projector[3:cfg.projector.index("x")])
+        specs += [("model.mm_projector.0.weight", (H, cfg.mm_hidden), std, 0.0), ("model.mm_projector.0.bias", (H,), std, 0.0)]
+        for d in range(1, depth):
+            specs += [(f"model.mm_projector.{2 * d}.weight", (H, H), std, 0.0), (f"model.mm_projector.{2 * d}.bias", (H,), std, 0.0)]
+    return specs
+
+
+def make_llama_weights_16bit(cfg: LlamaCfg, seed: int = 0, std: float = 0.02, head_std: float | None = None, dtype: str = "float16",
+                             workers: int | None = None) -> dict:
+    """Full-size (7B / 13B) seeded state dict as 16-bit TORCH tensors -- what a released checkpoint is.  Every tensor has its own
+    PCG64 stream (seeded with [seed, index]) and is filled by a thread pool (numpy releases the GIL), so 6.7e9 weights take seconds on
+    a many-core host instead of minutes, with bit-identical values on any machine and any worker count."""
+    import concurrent.futures
+    import os
+    import torch
+    tdt = {"float16": torch.float16, "bfloat16": torch.bfloat16}[dtype]
+    specs = llama_tensor_specs(cfg, std, head_std)
+
+    def fill(job):
+        idx, (key, shape, s, off) = job
+        rng = np.random.default_rng([seed, idx])
+        out = torch.empty(shape, dtype=tdt)
+        rows = shape[0]
+        step = max(1, (1 << 24) // max(1, int(np.prod(shape[1:], dtype=np.int64))))        # ~64 MB fp32 pieces
+        for r0 in range(0, rows, step):
+            n = min(step, rows - r0)
+            a = rng.standard_normal((n,) + tuple(shape[1:]), dtype=np.float32)
+            a *= np.float32(s)
+            if off:
+                a += np.float32(off)
+            out[r0:r0 + n] = torch.from_numpy(a).to(tdt)
+        return key, out
+
+    workers = workers or min(32, os.cpu_count() or 8)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=workers) as ex:
+        return dict(ex.map(fill, enumerate(specs)))
+
+
 def make_frames(n_frames: int, size: int = 224, seed: int = 0) -> np.ndarray:
     """Synthetic clip: uint8 [T, size, size, 3] (default_rng(seed).integers(0,256))."""
     return np.random.default_rng(seed).integers(0, 256, (n_frames, size, size, 3), dtype=np.uint8)

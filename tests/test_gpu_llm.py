@@ -22,18 +22,7 @@ def rel(a, b) -> float:
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
-def _model(cfg: synth.LlamaCfg, w: dict, dtype, image=224):
-    from video_llava_amd.model.video_chatgpt import VideoChatGPTConfig, VideoChatGPTLlamaForCausalLM, VisionConfig
-    hc = VideoChatGPTConfig(vocab_size=cfg.vocab, hidden_size=cfg.hidden, intermediate_size=cfg.inter,
-                            num_hidden_layers=cfg.layers, num_attention_heads=cfg.heads, rms_norm_eps=cfg.eps,
-                            rope_theta=cfg.rope_theta, mm_hidden_size=cfg.mm_hidden, mm_projector_type=cfg.projector,
-                            eos_token_id=None)
-    m = VideoChatGPTLlamaForCausalLM(hc, VisionConfig(frame_size=image), dtype)
-    st = m.load_state_dict(w)
-    assert not st.unexpected_keys and not st.missing_keys
-    vc = m.get_model().vision_config
-    vc.vid_patch_token, vc.vid_start_token, vc.vid_end_token, vc.use_vid_start_end = cfg.vocab - 3, cfg.vocab - 2, cfg.vocab - 1, True
-    return m
+from helpers import make_model as _model  # noqa: E402
 
 
 @pytest.mark.parametrize("tag,proj,image", [("lin", "linear", 224), ("mlp", "mlp2x_gelu", 336)])
@@ -57,14 +46,17 @@ def test_tiny_llama_golden(ctx, golden_dir, tag, proj, image, dtype, tol):
         nxt, lg = m.decode_step(kv, nxt, want_logits=True)
         assert rel(lg[0], g[tag + "_step_logits"][i]) < tol, i
         got.append(int(nxt[0]))
-    if dtype == torch.float16:
-        assert got == toks_ref                          # token-exact greedy
+    # token-exact greedy: always in fp16 (fixture margins 0.12 / 0.042 vs ~0.002 of fp16 logit noise); in bf16 (noise ~0.02) for the `lin`
+    # fixture, whose smallest margin is 6 sigma -- the `mlp` fixture's 0.042 is not, so only its logits are bounded in bf16
+    exact = dtype == torch.float16 or tag == "lin"
+    if exact:
+        assert got == toks_ref
     # generate(): prompt echoed, same tokens, chunked device-side greedy loop
     out = m.generate(torch.tensor([ids]), video_spatio_temporal_features=feats[None].to(dtype), do_sample=False,
                      max_new_tokens=n, chunk=5)
     assert out.shape == (1, len(ids) + n)
     assert out[0, :len(ids)].tolist() == ids
-    if dtype == torch.float16:
+    if exact:
         assert out[0, len(ids):].tolist() == toks_ref
 
 
@@ -92,7 +84,7 @@ def test_splice_errors_and_text_only(ctx, golden_dir):
 def test_ragged_batch_matches_single(ctx, golden_dir):
     """Data-parallel unit = one clip; batching clips on a GPU must not change any clip's answer."""
     cfg = synth.LLAMA_TINY
-    w = synth.make_llama_weights(cfg, seed=3, head_std=0.08)
+    w = synth.make_llama_weights(cfg, seed=8, head_std=0.08)     # seed searched on the CPU: every prompt's 10 margins > 0.04 (asserted below)
     m = _model(cfg, w, torch.float16)
     rng = np.random.default_rng(0)
     PATCH, START, END = cfg.vocab - 3, cfg.vocab - 2, cfg.vocab - 1
@@ -110,8 +102,8 @@ def test_ragged_batch_matches_single(ctx, golden_dir):
     for i, p in enumerate(prompts):
         assert batch[i, len(p):len(p) + n].tolist() == singles[i]
         ref, margins = ollm.greedy_generate(w, cfg, p, feats[i], START, END, PATCH, n, return_margins=True)
-        if min(margins) > 0.02:
-            assert singles[i] == ref
+        assert min(margins) > 0.03, (i, margins)             # ~15x the fp16 logit noise of this model: the comparison below is never vacuous
+        assert singles[i] == ref
 
 
 @pytest.mark.parametrize("seed", [11, 12, 13, 14])
@@ -140,6 +132,9 @@ def test_ragged_batch_random_shapes(ctx, seed):
         assert batch[i, len(p):len(p) + n].tolist() == single, (seed, B, i, len(p))
 
 
+TWO_LAYER_SEED = {"7b": 11, "13b": 8}      # 13B: margins 0.61 (fp16) / 0.50 (bf16)
+
+
 @pytest.mark.parametrize("shape", ["7b", "13b"])
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 3e-3), (torch.bfloat16, 2.4e-2)])
 def test_7b_shaped_two_layers_vs_oracle(ctx, dtype, tol, shape):
@@ -149,8 +144,9 @@ def test_7b_shaped_two_layers_vs_oracle(ctx, dtype, tol, shape):
     at width 4096 every 16-bit intermediate (normed x, q/k/v, probabilities, attention out, SwiGLU act, projected
     video rows) contributes ~2.8e-4 rms, ~16 of them over two layers -> ~1.5e-3 measured; the residual stream itself is fp32."""
     cfg = synth.LlamaCfg(layers=2) if shape == "7b" else synth.LlamaCfg(layers=2, hidden=5120, inter=13824, heads=40)
-    # checkpoints are 16-bit: both the oracle and the HIP path get the same 16-bit-valued weights
-    w = synth.quantize_weights(synth.make_llama_weights(cfg, seed=7, head_std=0.05), str(dtype).split(".")[1])
+    # checkpoints are 16-bit: both the oracle and the HIP path get the same 16-bit-valued weights.  Weight seeds searched on the CPU so
+    # that all six greedy steps have an oracle margin > 0.3 in both dtypes (7B: 0.39 / 0.32; 13B: see TWO_LAYER_SEED) -- asserted below.
+    w = synth.quantize_weights(synth.make_llama_weights(cfg, seed=TWO_LAYER_SEED[shape], head_std=0.05), str(dtype).split(".")[1])
     m = _model(cfg, w, dtype)
     rng = np.random.default_rng(1)
     PATCH, START, END = cfg.vocab - 3, cfg.vocab - 2, cfg.vocab - 1
@@ -166,8 +162,9 @@ def test_7b_shaped_two_layers_vs_oracle(ctx, dtype, tol, shape):
     assert e < tol
     toks_ref, margins = ollm.greedy_generate(w, cfg, ids, feats, START, END, PATCH, n, return_margins=True)
     toks = [int(nxt[0])] + m.decode_greedy(kv, nxt, n - 1)[0].tolist()
-    if dtype == torch.float16 and min(margins) > 0.05:
-        assert toks == toks_ref
+    print(f"{shape}-shaped 2-layer oracle margins ({dtype}): {[round(x, 3) for x in margins]}")
+    assert min(margins) > 0.3, margins                       # > 5 sigma of the bf16 logit noise at this width (0.06), ~70 sigma in fp16
+    assert toks == toks_ref, (toks, toks_ref, margins)       # token-exact in fp16 AND bf16
 
 
 def test_kv_bounds_and_errors(ctx):
@@ -278,7 +275,7 @@ def test_gemv_fp8_bit_equal_to_16bit_on_dequantised(ctx, dtype, mode, N, K, B):
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 1e-3), (torch.bfloat16, 8e-3)])
 def test_llm_fp8_weights_vs_oracle(ctx, golden_dir, dtype, tol):
     cfg = synth.LlamaCfg(**{**synth.LLAMA_TINY.__dict__, "projector": "linear"})
-    w = synth.make_llama_weights(cfg, seed=77, head_std=0.08)
+    w = synth.make_llama_weights(cfg, seed=78, head_std=0.08)   # seed searched on the CPU: margins of all 8 steps > 0.3 in fp16 and bf16
     m = _model(cfg, w, dtype).quantize_weights_fp8()
     assert m.is_fp8
     wq = ollm.quantize_llama_weights_fp8(w, round16=dtype)
@@ -292,8 +289,8 @@ def test_llm_fp8_weights_vs_oracle(ctx, golden_dir, dtype, tol):
     ref, margins = ollm.greedy_generate(wq, cfg, ids, feats, cfg.vocab - 2, cfg.vocab - 1, cfg.vocab - 3, NEW, return_margins=True)
     out = m.generate(torch.tensor([ids]), video_spatio_temporal_features=feats.to(dtype)[None], do_sample=False, max_new_tokens=NEW)
     got = out[0, len(ids):].tolist()
-    k = next((i for i, mg in enumerate(margins) if mg < 0.02), NEW)
-    assert got[:k] == ref[:k], (got, ref, margins)
+    assert min(margins) > 0.25, margins                       # > 10x the bf16 logit noise of this model: never vacuous
+    assert got == ref, (got, ref, margins)                    # token-exact in fp16 and bf16
     # a second model loaded with the dequantised weights (no fp8) produces the same logits bit for bit: prefill reads the 16-bit
     # copy, decode the fp8 copy
     m2 = _model(cfg, wq, dtype)

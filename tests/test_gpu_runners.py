@@ -17,12 +17,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _tower(ccfg, cw, dtype=torch.float16):
-    from video_llava_amd.vision_tower import CLIPVisionTower, CLIPVisionTowerConfig
-    t = CLIPVisionTower(CLIPVisionTowerConfig(hidden_size=ccfg.hidden, intermediate_size=ccfg.inter, num_hidden_layers=ccfg.layers,
-                                              num_attention_heads=ccfg.heads, image_size=ccfg.image, patch_size=ccfg.patch), dtype)
-    t.load_state_dict(cw)
-    return t
+from helpers import SynthTokenizer as _Tok, make_tower as _tower  # noqa: E402
 
 
 def test_extraction_loop_writes_reference_format(ctx, tmp_path):
@@ -53,35 +48,6 @@ def test_extraction_loop_writes_reference_format(ctx, tmp_path):
         assert err < 1e-3, (k, err)
         T = frames.shape[0]
         assert not got[T:100].any()
-
-
-class _Tok:
-    """Synthetic tokenizer exposing exactly the calls the path makes: ids are byte values + 3, the three video tokens
-    sit at the top of the vocabulary."""
-
-    def __init__(self, vocab):
-        self.vocab = vocab
-        self.special = {"<vid_patch>": vocab - 3, "<vid_start>": vocab - 2, "<vid_end>": vocab - 1}
-
-    def _encode(self, s):
-        ids, i = [1], 0
-        while i < len(s):
-            for name, tid in self.special.items():
-                if s.startswith(name, i):
-                    ids.append(tid); i += len(name)
-                    break
-            else:
-                ids.append(3 + (ord(s[i]) % (self.vocab - 8))); i += 1
-        return ids
-
-    def __call__(self, x):
-        class R: pass
-        r = R()
-        r.input_ids = [self._encode(t) for t in x] if isinstance(x, (list, tuple)) else self._encode(x)
-        return r
-
-    def batch_decode(self, ids, skip_special_tokens=True):
-        return [" ".join(str(int(t)) for t in row) for row in ids]
 
 
 def test_qa_runner_end_to_end_matches_oracle(ctx, tmp_path):
@@ -129,8 +95,8 @@ def test_qa_runner_end_to_end_matches_oracle(ctx, tmp_path):
         ids = tok([prompt]).input_ids[0]
         ref, margins = ollm.greedy_generate(lw, lcfg, ids, pooled.float(), lcfg.vocab - 2, lcfg.vocab - 1, lcfg.vocab - 3, NEW, return_margins=True)
         got = [int(t) for t in o["pred"].split()]
-        k = next((i for i, m in enumerate(margins) if m < 0.02), NEW)           # compare up to the first near-tie of the oracle
-        assert got[:k] == ref[:k], (n, got, ref, margins)
+        assert min(margins) > 0.5, margins          # seeds (21, 22): every step's oracle margin is 0.9+ -- the comparison is never vacuous
+        assert got == ref, (n, got, ref, margins)
 
 
 def test_consistency_runner_end_to_end_matches_oracle(ctx, tmp_path):
@@ -141,7 +107,7 @@ def test_consistency_runner_end_to_end_matches_oracle(ctx, tmp_path):
     from video_llava_amd.model.video_chatgpt import VideoChatGPTConfig, VideoChatGPTLlamaForCausalLM, VisionConfig
     ccfg, lcfg = synth.CLIP_TINY, synth.LLAMA_TINY
     cw = synth.make_clip_weights(ccfg, seed=41)
-    lw = synth.make_llama_weights(lcfg, seed=42, head_std=0.08)
+    lw = synth.make_llama_weights(lcfg, seed=39, head_std=0.08)      # searched: all four answers' margins > 0.35
     tower = _tower(ccfg, cw)
     model = VideoChatGPTLlamaForCausalLM(VideoChatGPTConfig(vocab_size=lcfg.vocab, hidden_size=lcfg.hidden, intermediate_size=lcfg.inter,
                                                             num_hidden_layers=lcfg.layers, num_attention_heads=lcfg.heads, eos_token_id=None,
@@ -175,8 +141,8 @@ def test_consistency_runner_end_to_end_matches_oracle(ctx, tmp_path):
             ref, margins = ollm.greedy_generate(lw, lcfg, tok([prompt]).input_ids[0], pooled.float(), lcfg.vocab - 2, lcfg.vocab - 1, lcfg.vocab - 3, NEW,
                                                 return_margins=True)
             got = [int(t) for t in o[pk].split()]
-            k = next((i for i, m in enumerate(margins) if m < 0.02), NEW)
-            assert got[:k] == ref[:k], (o["video_name"], qk, got, ref, margins)
+            assert min(margins) > 0.3, margins
+            assert got == ref, (o["video_name"], qk, got, ref, margins)
 
 
 def test_chat_interface_multi_turn_matches_oracle(ctx, tmp_path):
@@ -188,7 +154,7 @@ def test_chat_interface_multi_turn_matches_oracle(ctx, tmp_path):
     from video_llava_amd.video_conversation import conv_templates
     ccfg, lcfg = synth.CLIP_TINY, synth.LLAMA_TINY
     cw = synth.make_clip_weights(ccfg, seed=41)
-    lw = synth.make_llama_weights(lcfg, seed=42, head_std=0.08)
+    lw = synth.make_llama_weights(lcfg, seed=39, head_std=0.08)      # searched: both turns' margins > 0.4
     tower = _tower(ccfg, cw)
     calls = {"n": 0}
     orig_call = type(tower).__call__
@@ -227,8 +193,8 @@ def test_chat_interface_multi_turn_matches_oracle(ctx, tmp_path):
             prompt = conv.get_prompt().replace("<video>", replace, 1)
             ids = tok([prompt]).input_ids[0]
             ref, margins = ollm.greedy_generate(lw, lcfg, ids, pooled.float(), lcfg.vocab - 2, lcfg.vocab - 1, lcfg.vocab - 3, NEW, return_margins=True)
-            k = next((i for i, m in enumerate(margins) if m < 0.02), NEW)
-            assert [int(t) for t in got.split()][:k] == ref[:k], (turn, got, ref, margins)
+            assert min(margins) > 0.3, margins
+            assert [int(t) for t in got.split()] == ref, (turn, got, ref, margins)
             conv.messages[-1][-1] = got
         assert calls["n"] == 1, "the CLIP tower must run once per uploaded clip, not once per turn"
         chat.clear_history()

@@ -313,3 +313,40 @@ def test_projector(ctx, dtype, tol, kind, rows):
     _lib.check(ctx.lib.pgv_projector(ctx.handle, _lib.dtype_code(dtype), len(ws), wp, bp, 1024, 4096, xd.data_ptr(), rows,
                                      y.data_ptr(), _lib.stream_ptr()))
     assert rel(y, ref) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("h,w,s", [(360, 640, 224), (360, 640, 336), (20, 20, 56), (481, 853, 224), (224, 224, 224), (112, 112, 224), (1080, 1920, 336)])
+def test_ingest_native_resolution_bit_exact(ctx, dtype, h, w, s):
+    """pgv_ingest_u8 = load_video's nearest resize (reference eval/model_utils.py:38-43: F.interpolate default mode on the
+    float tensor, cast back to uint8) fused with CLIPImageProcessor's normalisation.  Integer-valued inputs, so the bar is BIT-exact
+    against the two-step path: torch's own interpolate on the host, then the (already oracle-checked) crop-size preprocessing kernel --
+    for down-sampling, up-sampling, non-integer ratios and the identity."""
+    from video_llava_amd.feature_extraction import resize_nearest
+    frames = np.random.default_rng(h * 3 + s).integers(0, 256, (3, h, w, 3), dtype=np.uint8)
+    fused = ctx.ingest_u8(torch.from_numpy(frames).to(DEV), s, dtype)
+    two_step = ctx.preprocess_u8(torch.from_numpy(np.ascontiguousarray(resize_nearest(frames, (s, s)))).to(DEV), dtype)
+    assert fused.shape == (3, 3, s, s) and torch.equal(fused, two_step)
+    # and against the oracle's CLIPImageProcessor restatement (fp32) within one rounding of the 16-bit output
+    ref = ovis.clip_preprocess(resize_nearest(frames, (s, s)))
+    assert float((fused.float().cpu() - ref).abs().max()) <= (2e-3 if dtype == torch.float16 else 1.6e-2)
+
+
+def test_native_frames_route_through_ingest(ctx, tmp_path):
+    """load_video(..., device_resize=True) -> NativeFrames -> inference.frames_to_pixels takes the fused path and equals the host-resized
+    route bit for bit; a NativeFrames whose target is not the tower's crop size falls back to the caller's image_processor."""
+    from video_llava_amd import feature_extraction as fx
+    from video_llava_amd.inference import frames_to_pixels
+    from video_llava_amd.vision_tower import CLIPVisionTower, CLIPVisionTowerConfig
+    ccfg = synth.CLIP_TINY
+    tower = CLIPVisionTower(CLIPVisionTowerConfig(hidden_size=ccfg.hidden, intermediate_size=ccfg.inter, num_hidden_layers=ccfg.layers,
+                                                  num_attention_heads=ccfg.heads, image_size=ccfg.image, patch_size=ccfg.patch), torch.float16)
+    clip = np.random.default_rng(4).integers(0, 256, (130, 90, 160, 3), dtype=np.uint8)
+    np.save(tmp_path / "clip.npy", clip)
+    native = fx.load_video(str(tmp_path / "clip.npy"), shape=(ccfg.image, ccfg.image), device_resize=True)
+    assert isinstance(native, fx.NativeFrames) and native.array.shape == (100, 90, 160, 3)
+    host = fx.load_video(str(tmp_path / "clip.npy"), shape=(ccfg.image, ccfg.image))
+    assert host.shape == (100, ccfg.image, ccfg.image, 3)
+    a = frames_to_pixels(native, None, tower)
+    b = frames_to_pixels(host, None, tower)
+    assert torch.equal(a, b)

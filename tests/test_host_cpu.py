@@ -328,3 +328,55 @@ def test_sibling_runners_host_logic(tmp_path, monkeypatch):
     (tmp_path / "t.tsv").write_text("gif_name\tquestion\tdescription\tanswer\ng1\thow many?\ta cat\t2\ng9\twhere?\ta dog\tpark\n")
     r = tgif.run_inference(tgif.parse_args(common + ["--gt_file", str(tmp_path / "t.tsv")]))
     assert r == [{"gif_name": "g1", "question": "how many?", "description": "a cat", "answer": "2", "pred": "ans:how many?"}]
+
+
+def test_first_stop_length_equals_per_token_criterion_loop():
+    """_sharded's batched path cuts an answer where the reference's per-token loop would have stopped: first_stop_length must agree with
+    driving KeywordsStoppingCriteria token by token (HF calls it after every appended token; its first call only records the start)."""
+    from video_llava_amd.model.utils import KeywordsStoppingCriteria, first_stop_length
+
+    class Tok:
+        def __call__(self, s):
+            class R: pass
+            r = R(); r.input_ids = [1] + [ord(c) for c in s]
+            return r
+
+        def batch_decode(self, ids, skip_special_tokens=True):
+            return ["".join(chr(int(t)) for t in row if int(t) > 2) for row in ids]
+
+    tok = Tok()
+    rng = np.random.default_rng(0)
+    prompt = torch.tensor([[1, 70, 71]])
+    for trial in range(300):
+        n = int(rng.integers(1, 30))
+        toks = rng.choice([ord("a"), ord("b"), ord("#"), ord(" ")], n, p=[0.4, 0.3, 0.2, 0.1]).tolist()
+        stop = ["###", "#", "ab#"][trial % 3]
+        crit = KeywordsStoppingCriteria([stop], tok, prompt)
+        want = None
+        for i in range(1, n + 1):
+            if crit(torch.tensor([prompt[0].tolist() + toks[:i]]), None):
+                want = i
+                break
+        assert first_stop_length(toks, tok, [stop]) == want, (toks, stop)
+
+
+def test_gather_answers_distinguishes_empty_from_failed():
+    from video_llava_amd import parallel
+    toks = torch.tensor([[5, 6, 7], [0, 0, 0], [0, 0, 0], [9, 0, 0]], dtype=torch.int32)
+    lens = torch.tensor([4, 1, 0, 2], dtype=torch.int32)              # length + 1; 0 = failed
+    out = parallel.gather_answers(toks, lens, 4, 0, 1, length_offset=1)
+    assert out == [[5, 6, 7], [], None, [9]]
+
+
+def test_nearest_resize_index_rule():
+    """pgv_ingest_u8 implements F.interpolate(mode='nearest') as src = min(floorf(dst * (float)in / out), in - 1) per axis; pin that rule
+    against torch itself on the shapes load_video meets (reference eval/model_utils.py:38-43), including up-sampling and odd ratios."""
+    from video_llava_amd.feature_extraction import resize_nearest
+    rng = np.random.default_rng(0)
+    for (h, w, s) in ((360, 640, 224), (360, 640, 336), (20, 20, 56), (481, 853, 224), (224, 224, 224), (112, 112, 224), (1080, 1920, 336)):
+        a = rng.integers(0, 256, (2, h, w, 3), dtype=np.uint8)
+        got = resize_nearest(a, (s, s))
+        sh, sw = np.float32(h) / np.float32(s), np.float32(w) / np.float32(s)
+        iy = np.minimum(np.floor(np.arange(s, dtype=np.float32) * sh).astype(np.int64), h - 1)
+        ix = np.minimum(np.floor(np.arange(s, dtype=np.float32) * sw).astype(np.int64), w - 1)
+        assert np.array_equal(got, a[:, iy][:, :, ix]), (h, w, s)

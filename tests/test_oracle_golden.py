@@ -111,3 +111,65 @@ def test_fp8_twin_properties():
     amax = w.abs().amax(1, keepdim=True).clamp_min(1e-30)
     assert float(((d - w).abs() / amax).max()) <= 2.0 ** -4 + 1e-6          # 3 mantissa bits: half-ulp at the top binade = 16/448 < 2^-4
     assert not d[5].any()
+
+
+def test_loader_golden_oracle_on_checkpoint_tree(golden_dir, tmp_path):
+    """tests/golden/loader.npz was produced by the REFERENCE's initialize_model + forward on the synthetic checkpoint tree
+    (oracle/gen_golden.py::gen_loader).  Re-create the tree from its seeds and check the oracle side of the GPU loader test: the
+    tokenizer files reproduce the prompt ids, and the fp32 oracle fed with the tree's weights reproduces the reference's greedy tokens for
+    both splice branches (with / without <vid_start> <vid_end>)."""
+    from oracle import ckpt
+    g = np.load(os.path.join(golden_dir, "loader.npz"))
+    lcfg, ccfg = synth.LLAMA_TINY, synth.CLIP_TINY
+    info = ckpt.write_checkpoint_tree(str(tmp_path), lcfg, ccfg, clip_seed=int(g["clip_seed"]), llm_seed=int(g["llm_seed"]), head_std=float(g["head_std"]))
+    from transformers import AutoTokenizer
+    tok = AutoTokenizer.from_pretrained(info["llm"])
+    assert len(tok) == ckpt.BASE_VOCAB
+    tok.add_tokens(["<vid_patch>"], special_tokens=True)
+    tok.add_tokens(["<vid_start>", "<vid_end>"], special_tokens=True)
+    assert tok.convert_tokens_to_ids(["<vid_patch>", "<vid_start>", "<vid_end>"]) == [lcfg.vocab - 3, lcfg.vocab - 2, lcfg.vocab - 1]
+    assert tok([str(g["prompt"])]).input_ids[0] == g["ids"].tolist()
+    assert tok("</s>").input_ids == [1, 2]                                # the stop string is a 2-id keyword: only the text match can fire
+    frames = synth.make_frames(int(g["n_frames"]), ccfg.image, seed=int(g["frame_seed"]))
+    pooled = ovis.spatio_temporal_pool_torch(ovis.clip_select_features(ovis.clip_preprocess(frames), info["clip_weights"], ccfg))
+    assert float((pooled.float() - torch.from_numpy(g["pooled"]).float()).norm() / pooled.float().norm()) < 2e-3
+    PATCH, START, END = lcfg.vocab - 3, lcfg.vocab - 2, lcfg.vocab - 1
+    n = int(g["n_new"])
+    toks, margins = ollm.greedy_generate(info["weights"], lcfg, g["ids"].tolist(), pooled.float(), START, END, PATCH, n, return_margins=True)
+    assert min(margins) > 0.05 and toks == g["tokens"].tolist()
+    toks2, margins2 = ollm.greedy_generate(info["weights"], lcfg, g["ids_nose"].tolist(), pooled.float(), None, None, PATCH, n, return_margins=True)
+    assert min(margins2) > 0.05 and toks2 == g["tokens_nose"].tolist()
+    # mm_projector.bin carries exactly the keys the reference's trainer keeps (train/llava_trainer.py:33-36)
+    sd = torch.load(info["projector"], map_location="cpu")
+    assert sorted(sd) == ["model.embed_tokens.weight", "model.mm_projector.bias", "model.mm_projector.weight"]
+    assert sd["model.embed_tokens.weight"].shape == (lcfg.vocab, lcfg.hidden)
+
+
+def test_sampling_oracle_equals_hf_warpers():
+    """oracle.llm.sample_cdf == softmax(TopKLogitsWarper(50)(TemperatureLogitsWarper(0.2)(logits))) with HF's own classes (the
+    processors GenerationMixin builds for the reference's `do_sample=True, temperature=0.2`), and the inverse-CDF pick has the right
+    limiting cases."""
+    from transformers.generation.logits_process import TemperatureLogitsWarper, TopKLogitsWarper
+    g = torch.Generator().manual_seed(0)
+    logits = torch.randn(5, 1000, generator=g) * 3
+    ids = torch.zeros(5, 1, dtype=torch.long)
+    for temp, k in ((0.2, 50), (1.0, 50), (0.7, 7)):
+        hf = torch.softmax(TopKLogitsWarper(k)(ids, TemperatureLogitsWarper(temp)(ids, logits.double())), -1)
+        mine = ollm.sample_cdf(logits, temp, k)
+        assert torch.allclose(torch.cumsum(hf, -1), mine, atol=1e-12)
+        assert int((hf > 0).sum(-1).max()) == k
+    u = torch.rand(5, generator=g)
+    assert ollm.sample_pick(logits, u, 1e-4, 50)[0].tolist() == logits.argmax(-1).tolist()          # temperature -> 0: greedy
+    assert ollm.sample_pick(logits, u, 0.2, 1)[0].tolist() == logits.argmax(-1).tolist()            # top-1: greedy
+    tok, _ = ollm.sample_pick(logits, torch.zeros(5), 1.0, 0)
+    assert tok.tolist() == [0] * 5                                                                  # u = 0: the first index with mass
+    # empirical frequencies follow the distribution (chi-square on the 50 kept entries, 20000 draws)
+    n = 20000
+    uu = torch.rand(n, generator=g)
+    tok, _ = ollm.sample_pick(logits[:1].expand(n, -1), uu, 0.8, 50)
+    p = torch.diff(ollm.sample_cdf(logits[:1], 0.8, 50)[0], prepend=torch.zeros(1, dtype=torch.float64))
+    keep = p > 0
+    cnt = torch.bincount(tok, minlength=1000).double()
+    assert int(cnt[~keep].sum()) == 0
+    chi2 = float((((cnt[keep] - n * p[keep]) ** 2) / (n * p[keep])).sum())
+    assert chi2 < 100.0, chi2                                        # 49 degrees of freedom: P(chi2 > 100) ~ 2e-5
