@@ -140,7 +140,7 @@ def cpu_baseline_reference(args):
       (ii) decoder: LLaMA-7B/13B-shaped LlamaForCausalLM.forward, fp32, eager attention, lm_head on all positions as the reference computes it
            (model/video_chatgpt.py:226): prefill of the ~450-token prompt and 8 KV-cached decode steps at 8 and at 4 layers; the per-layer
            and fixed parts are separated by the difference and extended to the full depth (layers are identical, the extension is exact up
-           to timing noise).  Thread counts {all cores, 32, 8} are tried for the decode step (small GEMVs do not scale to 128 threads),
+           to timing noise).  Thread counts {torch default, 64, 32, 16, 8} are tried for the decode step (small GEMVs do not scale to 128 threads),
            the best is kept per stage."""
     import transformers
     from transformers import CLIPVisionConfig, CLIPVisionModel, LlamaConfig, LlamaForCausalLM
@@ -156,7 +156,7 @@ def cpu_baseline_reference(args):
     px = ovis.clip_preprocess(frames)
     vit_times = {}
     with torch.no_grad():
-        for th in sorted({default_threads, min(32, ncores), min(8, ncores)}, reverse=True):
+        for th in sorted({default_threads, min(32, ncores), min(16, ncores), min(8, ncores)}, reverse=True):
             torch.set_num_threads(th)
             clip(px[:1], output_hidden_states=True)                                   # warm-up
             best = 1e9
@@ -190,7 +190,7 @@ def cpu_baseline_reference(args):
                 o = llm(input_ids=tok, past_key_values=o.past_key_values, use_cache=True)
             return t_pre, (time.perf_counter() - t0) / n_step
 
-    cand = sorted({default_threads, min(32, ncores), min(8, ncores)}, reverse=True)
+    cand = sorted({default_threads, min(64, ncores), min(32, ncores), min(16, ncores), min(8, ncores)}, reverse=True)
     hi = {th: run(th) for th in cand}
     th_pre = min(hi, key=lambda t: hi[t][0])
     th_step = min(hi, key=lambda t: hi[t][1])

@@ -22,7 +22,8 @@ N_NEW = 16
 CASES = {
     # name: cfg, weight seed, prompt seed, head_std, asserted margin floor
     "7b": dict(cfg=synth.LLAMA_7B, weight_seed=7, prompt_seed=2, head_std=0.05, floor=0.1),      # searched: min margin 0.130 over 16 steps
-    "13b": dict(cfg=synth.LLAMA_13B, weight_seed=13, prompt_seed=0, head_std=0.05, floor=0.05),
+    # 13B: margins of the fp32 oracle on the fp8-DEQUANTISED fp16 weights (`search 13b 0 12 fp8`): prompt seed 4 -> min 0.265 over 16 steps
+    "13b": dict(cfg=synth.LLAMA_13B, weight_seed=13, prompt_seed=4, head_std=0.05, floor=0.2),
 }
 
 

@@ -339,3 +339,25 @@ def test_full_7b_batch_invariance(ctx, weights):
                 nxt, lg = m.decode_step(kv1, nxt, want_logits=True)
         del kv1
     assert torch.isfinite(steps_b[-1][1]).all()
+
+
+def test_greedy_pick_takes_the_first_index_on_ties(ctx):
+    """torch.argmax (the reference's greedy pick) returns the first maximal index.  With every lm_head row identical all logits of a step are
+    bitwise equal, so prefill, the chunked device-side greedy loop and the stepwise path must all pick token 0 -- through the per-workgroup
+    candidates of the lm_head GEMV (2001 workgroups at vocabulary 32003; 33 here) and the final reduction over them."""
+    cfg = synth.LLAMA_TINY
+    w = dict(synth.make_llama_weights(cfg, seed=5, head_std=0.08))
+    w["lm_head.weight"] = np.repeat(w["lm_head.weight"][7:8], cfg.vocab, axis=0)
+    m = _model(cfg, w, torch.float16)
+    ids = [1, 17, 230, 9, 44]
+    kv, nxt, lg = m.prefill([ids, ids[:3]], None, 64, want_logits=True)
+    assert bool((lg == lg[:, :1]).all()) and nxt.tolist() == [0, 0]
+    assert m.decode_greedy(kv, nxt, 6).tolist() == [[0] * 6, [0] * 6]
+    nxt2, lg2 = m.decode_step(kv, nxt, want_logits=True)
+    assert nxt2.tolist() == [0, 0] and bool((lg2 == lg2[:, :1]).all())
+    # a NaN logit is never picked: poison row 0 of lm_head -> logit 0 is NaN -> the pick moves to index 1
+    w["lm_head.weight"] = w["lm_head.weight"].copy()
+    w["lm_head.weight"][0, 0] = np.nan
+    m2 = _model(cfg, w, torch.float16)
+    kv, nxt, lg = m2.prefill([ids], None, 64, want_logits=True)
+    assert bool(torch.isnan(lg[0, 0])) and nxt.tolist() == [1]

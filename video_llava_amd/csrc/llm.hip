@@ -17,19 +17,21 @@ int pgv_launch_rope_kv_write(int dtype, void* qkv, const int* row_b, const int* 
 int pgv_launch_prefill_attn(pgv_ctx* ctx, int dtype, const void* qkv, void* out, const void* Kc, const void* Vc, const int* cu, int B, int max_len,
                             int H, int heads, int max_seq, double flops, hipStream_t s);
 int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void* x, int ldx, void* out, int ldo, int N, int K, int B, hipStream_t s,
-                    int splits = 1, const float* wscale = nullptr);
+                    int splits = 1, const float* wscale = nullptr, const GemvNorm* norm = nullptr);
+int pgv_launch_embed_tok_norm(int dtype, const int* tok, const void* embed, float* resid, const float* gamma, void* xg, float* ssq, int B, int H, hipStream_t s);
 int pgv_launch_quantize_fp8(int dtype, void* w16_blocked, void* w8_blocked, float* scales, long long N, long long K, hipStream_t s);
 int pgv_launch_unpack_blocked(int dtype, const void* src, float* dst, long long N, long long K, long long row_blk, long long blk_stride, long long row_off,
                               long long rows, hipStream_t s);
-int pgv_launch_rms_resid(int dtype, float* resid, const float* part, int nparts, int B, const float* gamma, float eps, void* xn, int H, hipStream_t s);
+int pgv_launch_final_prep(int dtype, const float* resid, const float* gamma, void* xg, float* ssq, int B, int H, hipStream_t s);
 int pgv_launch_decode_attn(pgv_ctx* ctx, int dtype, const void* qkv, const int* pos, const void* rope, void* Kc, void* Vc, void* out, int B, int H,
                            int heads, int max_seq, double bytes, hipStream_t s);
 int pgv_launch_argmax(const float* logits, int V, int B, int* next, int* pos, int* step, int* hist, int hist_stride, int* done, int eos, int flags,
                       hipStream_t s);
 int pgv_launch_sample(const float* logits, int V, int B, float temperature, int top_k, const float* u, int u_stride, int u_by_step, int* next, int* pos,
                       int* step, int* hist, int hist_stride, int* done, int eos, int advance, hipStream_t s);
-enum { GV_STORE16 = 0, GV_RESID = 1, GV_SWIGLU = 2, GV_F32 = 3, GV_PART = 4 };
-constexpr int kSplits = 2;      // split-K of the residual GEMVs (o_proj, down_proj) in decode
+int pgv_launch_argmax_parts(const float* val, const int* idx, int nblk, int V, int B, int* next, int* pos, int* step, int* hist, int hist_stride, int* done,
+                            int eos, int advance, hipStream_t s);
+enum { GV_STORE16 = 0, GV_RESID = 1, GV_SWIGLU = 2, GV_F32 = 3, GV_PART = 4, GV_RESIDNORM = 5 };
 enum { AM_INC_POS = 1, AM_RECORD = 2, AM_SAMPLE = 4 };
 
 constexpr int kMaxPos = 4096;   // max_position_embeddings of LLaVA-1.5 / Vicuna-1.5
@@ -68,7 +70,9 @@ struct pgv_kv {
     char* blob = nullptr;
     std::vector<void*> Kc, Vc;          // per layer [B][heads][max_seq][128]
     // fixed-address decode buffers (so a decode step can be captured into a hipGraph)
-    float* resid; void* xn; void* qkv; void* ao; void* act; float* logits; float* part;
+    float* resid; void* xn; void* qkv; void* ao; void* act; float* logits;
+    float* amax_val; int* amax_idx;     // greedy candidates of the lm_head GEMV: [vocab_cap / 16][16]
+    float* ssq;                         // sum-of-squares partials of the folded RMSNorm: [hidden / 16][16] (see GemvArgs in llm_kernels.hip)
     int *d_pos, *d_cur, *d_step, *d_done, *d_hist;
     std::vector<int> h_len;
     std::vector<int> h_meta;           // staging for prefill row maps (kept alive across the async copy)
@@ -296,17 +300,18 @@ extern "C" int pgv_kv_create(pgv_ctx* ctx, pgv_llm* llm, int batch, int max_seq,
     auto take = [&](size_t bytes) { size_t o = off; off += pgv_align(bytes); return o; };
     const size_t o_cache = take(per * 2 * L);
     const size_t o_resid = take(B * H * 4), o_xn = take(B * H * 2), o_qkv = take(B * 3 * H * 2), o_ao = take(B * H * 2), o_act = take(B * I * 2),
-                 o_logits = take(B * V * 4), o_part = take((size_t)kSplits * B * H * 4), o_ints = take((4 * B + B * (size_t)max_seq) * 4),
+                 o_logits = take(B * V * 4), o_ssq = take((H / 16) * 16 * 4), o_av = take((V / 16) * 16 * 4), o_ai = take((V / 16) * 16 * 4), o_ints = take((4 * B + B * (size_t)max_seq) * 4),
                  o_u = take(B * (size_t)max_seq * 4);
     hipError_t e = hipMalloc((void**)&kv->blob, off);
     if (e != hipSuccess) { delete kv; pgv_set_error("pgv_kv_create: hipMalloc(%zu MiB): %s", off >> 20, hipGetErrorString(e)); return PGV_ENOMEM; }
     char* b = kv->blob;
     for (size_t i = 0; i < L; ++i) { kv->Kc.push_back(b + o_cache + per * 2 * i); kv->Vc.push_back(b + o_cache + per * (2 * i + 1)); }
-    kv->resid = (float*)(b + o_resid); kv->xn = b + o_xn; kv->qkv = b + o_qkv; kv->ao = b + o_ao; kv->act = b + o_act; kv->logits = (float*)(b + o_logits); kv->part = (float*)(b + o_part);
+    kv->resid = (float*)(b + o_resid); kv->xn = b + o_xn; kv->qkv = b + o_qkv; kv->ao = b + o_ao; kv->act = b + o_act; kv->logits = (float*)(b + o_logits); kv->ssq = (float*)(b + o_ssq); kv->amax_val = (float*)(b + o_av); kv->amax_idx = (int*)(b + o_ai);
     int* ints = (int*)(b + o_ints);
     kv->d_pos = ints; kv->d_cur = ints + B; kv->d_step = ints + 2 * B; kv->d_done = ints + 3 * B; kv->d_hist = ints + 4 * B;
     kv->d_u = (float*)(b + o_u);
     e = hipMemset(ints, 0, (4 * B + B * (size_t)max_seq) * 4);
+    if (e == hipSuccess) e = hipMemset(kv->ssq, 0, (H / 16) * 16 * 4);
     if (e != hipSuccess) { (void)hipFree(kv->blob); delete kv; pgv_set_error("pgv_kv_create: memset: %s", hipGetErrorString(e)); return PGV_EHIP; }
     kv->h_len.assign(batch, 0);
     *out = kv;
@@ -325,18 +330,21 @@ extern "C" int pgv_kv_len(const pgv_kv* kv, int b) { return (kv && b >= 0 && b <
 // ---------------------------------------------------------------------------------------------
 // shared tail: final norm + lm_head + argmax on kv->resid [B,H]
 // ---------------------------------------------------------------------------------------------
-static int lm_head_and_pick(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int B, int eos, int flags, hipStream_t s, int nparts = 0) {
+// kv->xn holds round16(resid * norm_g) and kv->ssq the `nparts` sum-of-squares partials of resid (folded final RMSNorm): lm_head scales its
+// fp32 accumulators by rstd.
+static int lm_head_and_pick(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int B, int eos, int flags, hipStream_t s, int nparts) {
     const int H = m->cfg.hidden, V = m->cfg.vocab;
-    pgv_prof_begin(ctx, 6, s);
-    PGV_TRY(pgv_launch_rms_resid(m->dtype, kv->resid, kv->part, nparts, B, m->norm_g, m->cfg.eps, kv->xn, H, s));
-    pgv_prof_end(ctx, 6, s, 0.0, 0.0);
-    PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_F32, m->fp8 ? m->q_head : m->lm_head, kv->xn, H, kv->logits, V, V, H, B, s, 1, m->fp8 ? m->s_head : nullptr));
+    GemvNorm nm; nm.ssq_in = kv->ssq; nm.nparts_in = nparts; nm.hidden = H; nm.eps = m->cfg.eps;
+    const bool greedy = !(flags & AM_SAMPLE);
+    if (greedy) { nm.amax_val = kv->amax_val; nm.amax_idx = kv->amax_idx; }
+    PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_F32, m->fp8 ? m->q_head : m->lm_head, kv->xn, H, kv->logits, V, V, H, B, s, 1, m->fp8 ? m->s_head : nullptr, &nm));
     pgv_prof_begin(ctx, 6, s);
     if (flags & AM_SAMPLE)
         PGV_TRY(pgv_launch_sample(kv->logits, V, B, kv->s_temp, kv->s_topk, kv->d_u, B, 1, kv->d_cur, kv->d_pos, kv->d_step, kv->d_hist, kv->max_seq, kv->d_done,
                                   eos, flags & (AM_INC_POS | AM_RECORD), s));
     else
-        PGV_TRY(pgv_launch_argmax(kv->logits, V, B, kv->d_cur, kv->d_pos, kv->d_step, kv->d_hist, kv->max_seq, kv->d_done, eos, flags, s));
+        PGV_TRY(pgv_launch_argmax_parts(kv->amax_val, kv->amax_idx, (V + 15) / 16, V, B, kv->d_cur, kv->d_pos, kv->d_step, kv->d_hist, kv->max_seq, kv->d_done, eos,
+                                        flags, s));
     pgv_prof_end(ctx, 6, s, 0.0, 0.0);
     return PGV_OK;
 }
@@ -415,7 +423,8 @@ extern "C" int pgv_llm_prefill(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, const int32
     }
     // lm_head only on the last position of every sequence (the reference computes all S positions, video_chatgpt.py:226)
     PGV_TRY(pgv_launch_gather_rows(resid, d_last, kv->resid, B, H, s));
-    PGV_TRY(lm_head_and_pick(ctx, m, kv, B, -1, 0, s));
+    PGV_TRY(pgv_launch_final_prep(m->dtype, kv->resid, m->norm_g, kv->xn, kv->ssq, B, H, s));
+    PGV_TRY(lm_head_and_pick(ctx, m, kv, B, -1, 0, s, 1));
     if (d_logits) PGV_HIP(hipMemcpyAsync(d_logits, kv->logits, (size_t)B * vocab * 4, hipMemcpyDeviceToDevice, s));
     if (d_next) PGV_HIP(hipMemcpyAsync(d_next, kv->d_cur, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
     for (int b = 0; b < kv->B; ++b) kv->h_len[b] = b < B ? h_seq_lens[b] : 0;
@@ -428,29 +437,31 @@ extern "C" int pgv_llm_prefill(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, const int32
 // decode
 // ---------------------------------------------------------------------------------------------
 static int decode_enqueue(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int eos, int flags, hipStream_t s) {
-    const int H = m->cfg.hidden, I = m->cfg.inter, heads = m->cfg.heads, B = kv->active;
+    const int H = m->cfg.hidden, I = m->cfg.inter, heads = m->cfg.heads, B = kv->active, L = m->cfg.layers;
+    const int nparts = H / 16;                     // one sum-of-squares partial per 16-row workgroup of a residual producer
+    // RMSNorm has no launch of its own in decode (GemvArgs, llm_kernels.hip): the kernel that completes the residual also writes
+    // xg = round16(resid * gamma_next) and sum-of-squares partials; the consumer GEMV scales its accumulators by rstd.
     pgv_prof_begin(ctx, 6, s);
-    PGV_TRY(pgv_launch_embed_tok(m->dtype, kv->d_cur, m->embed, kv->resid, B, H, s));
+    PGV_TRY(pgv_launch_embed_tok_norm(m->dtype, kv->d_cur, m->embed, kv->resid, L > 0 ? m->layers[0].in_g : m->norm_g, kv->xn, kv->ssq, B, H, s));
     pgv_prof_end(ctx, 6, s, 0.0, 0.0);
     double kv_bytes = 0;
     for (int b = 0; b < B; ++b) kv_bytes += 2.0 * 2.0 * (double)(kv->h_len[b] + 1) * H;
-    for (int li = 0; li < m->cfg.layers; ++li) {
+    int parts_in = 1;                              // the embedding kernel leaves one partial per sequence
+    for (int li = 0; li < L; ++li) {
         const LlmLayer& l = m->layers[li];
-        // input norm; for li > 0 it also folds the previous layer's down_proj split-K partials into the residual
-        pgv_prof_begin(ctx, 6, s);
-        PGV_TRY(pgv_launch_rms_resid(m->dtype, kv->resid, kv->part, li == 0 ? 0 : kSplits, B, l.in_g, m->cfg.eps, kv->xn, H, s));
-        pgv_prof_end(ctx, 6, s, 0.0, 0.0);
         const bool q8 = m->fp8;
-        PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_STORE16, q8 ? l.q_wqkv : l.wqkv, kv->xn, H, kv->qkv, 3 * H, 3 * H, H, B, s, 1, q8 ? l.s_wqkv : nullptr));
+        GemvNorm cons; cons.ssq_in = kv->ssq; cons.nparts_in = parts_in; cons.hidden = H; cons.eps = m->cfg.eps;
+        PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_STORE16, q8 ? l.q_wqkv : l.wqkv, kv->xn, H, kv->qkv, 3 * H, 3 * H, H, B, s, 1, q8 ? l.s_wqkv : nullptr, &cons));
         PGV_TRY(pgv_launch_decode_attn(ctx, m->dtype, kv->qkv, kv->d_pos, m->rope, kv->Kc[li], kv->Vc[li], kv->ao, B, H, heads, kv->max_seq, kv_bytes, s));
-        PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_PART, q8 ? l.q_wo : l.wo, kv->ao, H, kv->part, H, H, H, B, s, kSplits, q8 ? l.s_wo : nullptr));
-        pgv_prof_begin(ctx, 6, s);
-        PGV_TRY(pgv_launch_rms_resid(m->dtype, kv->resid, kv->part, kSplits, B, l.post_g, m->cfg.eps, kv->xn, H, s));
-        pgv_prof_end(ctx, 6, s, 0.0, 0.0);
-        PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_SWIGLU, q8 ? l.q_wgu : l.wgu, kv->xn, H, kv->act, I, 2 * I, H, B, s, 1, q8 ? l.s_wgu : nullptr));
-        PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_PART, q8 ? l.q_wdown : l.wdown, kv->act, I, kv->part, H, H, I, B, s, kSplits, q8 ? l.s_wdown : nullptr));
+        GemvNorm prod; prod.gamma = l.post_g; prod.xg = kv->xn; prod.ssq_out = kv->ssq;
+        PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_RESIDNORM, q8 ? l.q_wo : l.wo, kv->ao, H, kv->resid, H, H, H, B, s, 1, q8 ? l.s_wo : nullptr, &prod));
+        cons.nparts_in = nparts;
+        PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_SWIGLU, q8 ? l.q_wgu : l.wgu, kv->xn, H, kv->act, I, 2 * I, H, B, s, 1, q8 ? l.s_wgu : nullptr, &cons));
+        prod.gamma = li + 1 < L ? m->layers[li + 1].in_g : m->norm_g;
+        PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_RESIDNORM, q8 ? l.q_wdown : l.wdown, kv->act, I, kv->resid, H, H, I, B, s, 1, q8 ? l.s_wdown : nullptr, &prod));
+        parts_in = nparts;
     }
-    PGV_TRY(lm_head_and_pick(ctx, m, kv, B, eos, flags, s, m->cfg.layers > 0 ? kSplits : 0));
+    PGV_TRY(lm_head_and_pick(ctx, m, kv, B, eos, flags, s, parts_in));
     return PGV_OK;
 }
 

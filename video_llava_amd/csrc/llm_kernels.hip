@@ -6,6 +6,8 @@
 //                    every weight byte is read exactly once, split-K across the 8 waves of a workgroup)
 //   decode_attn    : RoPE + cache append + single-query attention over the cache (flash-decoding style)
 //   argmax         : greedy token + per-sequence bookkeeping (position, step, EOS stickiness) on the device
+#include <stdlib.h>
+
 #include "pgv_common.h"
 
 namespace {
@@ -260,32 +262,66 @@ __global__ __launch_bounds__(256) void prefill_attn_kernel(PrefillAttnArgs p) {
 // Workgroup = 8 waves, owns TILES row blocks; wave w takes k-steps w, w+8, ... (adjacent KiBs of the same row block).
 // B operand = x fragment (lane: batch l&15, k (l>>4)*8..+8) served by L2.  Partial 16x16 tiles are reduced through LDS.
 // ---------------------------------------------------------------------------------------------
-enum { GV_STORE16 = 0, GV_RESID = 1, GV_SWIGLU = 2, GV_F32 = 3, GV_PART = 4 };
+enum { GV_STORE16 = 0, GV_RESID = 1, GV_SWIGLU = 2, GV_F32 = 3, GV_PART = 4, GV_RESIDNORM = 5 };
 
+// Buffer descriptor over `bytes` bytes at `base` from provably wave-uniform inputs (cdna_hip_programming.md T20): lanes whose voffset lies outside
+// the range are dropped by the hardware -- no memory request, the result is 0.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t gv_make_rsrc(const void* base, unsigned bytes) {
+    const uintptr_t b = (uintptr_t)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
+// RMSNorm is folded into the GEMVs around it (decode only; no launch of its own):
+//   producer (GV_RESIDNORM: o_proj, down_proj; also the embedding gather): r = resid + y is written back in fp32, xg = round16(r * gamma) --
+//     gamma of the norm that FOLLOWS, known statically -- is written as the 16-bit operand of the next GEMV, and the sum of r^2 over the
+//     workgroup's 16 rows goes to ssq_out[workgroup][b];
+//   consumer (qkv, gate/up, lm_head): y = (W xg) * rstd[b] with rstd = rsqrt(sum_parts ssq / H + eps), applied to the fp32 accumulators.
+// W (r rstd gamma) = rstd W (r gamma) exactly in real arithmetic; in floating point the 16-bit rounding now happens before the scale by rstd
+// instead of after it -- the same relative error, no weight is modified, so the fp8 path keeps its bit-equality with the 16-bit path.
 struct GemvArgs {
     const char* W; const char* x; char* out;
     int N, K, B, ldx, ldo;
     int kb_per;     // k-blocks (of 32) per split; gridDim.y splits write fp32 partials [split][B][ldo] in GV_PART mode
     const float* wscale;   // W8 = true: per-row power-of-two scales of the fp8 matrix (fp8.hip)
+    // consumer side of the folded RMSNorm (null ssq_in: plain GEMV)
+    const float* ssq_in; int nparts_in; float inv_h, eps;      // ssq_in [nparts_in][16]
+    // producer side (GV_RESIDNORM): out = fp32 residual [B][ldo] (read-modify-write)
+    const float* gamma; char* xg; float* ssq_out;              // xg [B][ldo] 16-bit, ssq_out [gridDim.x][16]
+    // GV_F32 (lm_head): per-workgroup greedy candidates -- the largest logit of the workgroup's 16 rows and its (smallest) index per batch
+    // column -- so the token pick scans N / 16 candidates instead of N logits (null: not wanted)
+    float* amax_val; int* amax_idx;                            // [gridDim.x][16]
 };
 
 // W8 = true streams the fp8 (e4m3) blocked copy of the matrix: one 16-byte load per lane carries the A fragments of TWO consecutive
 // k-blocks, the codes are widened to the activation dtype in registers (exact) and the per-row scale multiplies the fp32 result, so the
 // output is bit-identical to the 16-bit kernel on the dequantised matrix while the weight stream is half as long.
+// 8 e4m3 codes -> 8 x 16-bit: v_cvt_scalef32_pk_{f16,bf16}_fp8 widens two codes per instruction (scale 1.0; e4m3 values are exactly
+// representable in fp16 and in bf16), 4 VALU per MFMA operand.  (Round 1 went through fp32 -- v_cvt_pk_f32_fp8 + a 16-bit pack, 16 VALU per
+// operand -- and the fp8 GEMVs were VALU-bound at 3.5 TB/s of fp8 bytes.)
 template <typename T>
 __device__ __forceinline__ typename T::v8 fp8x8_to_v8(unsigned lo, unsigned hi) {
-    const f32x2_t a = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, true);
-    const f32x2_t c = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, false), d = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, true);
+    typename T::v2 a, b, c, d;
+    if constexpr (T::id == PGV_F16) {
+        a = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(lo, 1.0f, false); b = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(lo, 1.0f, true);
+        c = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(hi, 1.0f, false); d = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(hi, 1.0f, true);
+    } else {
+        a = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, 1.0f, false); b = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, 1.0f, true);
+        c = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, 1.0f, false); d = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, 1.0f, true);
+    }
     typename T::v8 r;
-    r[0] = T::from_f32(a[0]); r[1] = T::from_f32(a[1]); r[2] = T::from_f32(b[0]); r[3] = T::from_f32(b[1]);
-    r[4] = T::from_f32(c[0]); r[5] = T::from_f32(c[1]); r[6] = T::from_f32(d[0]); r[7] = T::from_f32(d[1]);
+    r[0] = a[0]; r[1] = a[1]; r[2] = b[0]; r[3] = b[1]; r[4] = c[0]; r[5] = c[1]; r[6] = d[0]; r[7] = d[1];
     return r;
 }
 
-template <typename T, int MODE, bool W8>
-__global__ __launch_bounds__(512) void gemv_mfma_kernel(GemvArgs p) {
+// NW = waves per workgroup (the K split inside a workgroup).  8 everywhere except the residual producers, which cannot split K across
+// workgroups any more (the workgroup that owns 16 output rows must see their complete sums to emit xg and the sum of squares) and use 16
+// waves instead, so that a CU still has 16 waves' worth of weight loads in flight with one workgroup per CU.
+template <typename T, int MODE, bool W8, int NW>
+__global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
     constexpr int TILES = (MODE == GV_SWIGLU) ? 2 : 1;
-    __shared__ f32x4_t red[8][TILES][64];
+    __shared__ f32x4_t red[NW][TILES][64];
+    __shared__ f32x4_t ssq_red[NW][4];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kg = lane >> 4;
@@ -299,7 +335,33 @@ __global__ __launch_bounds__(512) void gemv_mfma_kernel(GemvArgs p) {
     } else {
         rb[0] = blockIdx.x;
     }
-    const char* xp = p.x + ((size_t)min(l15, p.B - 1) * p.ldx + kg * 8) * 2;
+    // folded RMSNorm, consumer side: this thread's share of the sum-of-squares partials (L2 hits), requested before the weight stream
+    // (three independent loads whose first USE is after the weight loop: summing them here would park the wave on an L2 round trip
+    // before its first weight load -- measured +1.4 us on the 18 us qkv GEMV)
+    constexpr int SSQ_LD = 3;                                   // 3 x NW x 64 float4 >= 4 x hidden / 16 up to hidden 6144
+    f32x4_t ssq_ld[SSQ_LD];
+    const bool scaled = (MODE == GV_STORE16 || MODE == GV_SWIGLU || MODE == GV_F32) && p.ssq_in != nullptr;
+    if (scaled) {
+        const int n4 = p.nparts_in * 4;
+#pragma unroll
+        for (int q = 0; q < SSQ_LD; ++q) ssq_ld[q] = ((const f32x4_t*)p.ssq_in)[min(tid + q * NW * 64, n4 - 1)];   // chunk (= 4 batch columns) index & 3 is fixed per thread
+    }
+    // producer side: the old residual and gamma are requested up front as well (by every wave; wave 0 consumes them in the epilogue)
+    f32x4_t r_old = {0.f, 0.f, 0.f, 0.f}, g_nx = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (MODE == GV_RESIDNORM) {
+        const int n0p = blockIdx.x * 16 + kg * 4;
+        r_old = *(const f32x4_t*)(p.out + ((size_t)min(l15, p.B - 1) * p.ldo + n0p) * 4);
+        g_nx = *(const f32x4_t*)(p.gamma + n0p);
+    }
+    // x fragment (MFMA B operand: lane = batch column l15, 8 consecutive k): an MFMA tile has 16 batch columns; the lanes of the columns
+    // >= B point outside the buffer descriptor, so they cost no request on the load path (with B = 8 half of every 1 KiB wave-load; the
+    // activations are re-read by every workgroup and the per-CU load path, not HBM, is what the fp8 GEMVs run into).  Their zeros only
+    // feed output columns that are never stored.
+    const __amdgpu_buffer_rsrc_t xrs = gv_make_rsrc(p.x, (unsigned)(((size_t)(p.B - 1) * p.ldx + p.K) * 2));
+    const unsigned xvo = l15 < p.B ? (unsigned)(((size_t)l15 * p.ldx + kg * 8) * 2) : 0x80000000u;
+    auto xload = [&](size_t kb) -> typename T::v8 {
+        return __builtin_bit_cast(typename T::v8, __builtin_amdgcn_raw_buffer_load_b128(xrs, xvo + (unsigned)(kb * 64), 0, 0));
+    };
     f32x4_t acc[TILES];
 #pragma unroll
     for (int t = 0; t < TILES; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -312,15 +374,15 @@ __global__ __launch_bounds__(512) void gemv_mfma_kernel(GemvArgs p) {
         constexpr int U = (TILES == 2) ? 4 : 8;
         const int j_end = min(k64, (int)(blockIdx.y + 1) * (p.kb_per >> 1));
         int j = blockIdx.y * (p.kb_per >> 1) + w;
-        for (; j + 8 * (U - 1) < j_end; j += 8 * U) {
+        for (; j + NW * (U - 1) < j_end; j += NW * U) {
             u32x4_t wr[U][TILES];
             typename T::v8 xf[U][2];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
 #pragma unroll
-                for (int t = 0; t < TILES; ++t) wr[u][t] = __builtin_nontemporal_load((const u32x4_t*)(wp[t] + (size_t)(j + 8 * u) * 1024));
-                xf[u][0] = *(const typename T::v8*)(xp + (size_t)(2 * (j + 8 * u)) * 64);
-                xf[u][1] = *(const typename T::v8*)(xp + (size_t)(2 * (j + 8 * u) + 1) * 64);
+                for (int t = 0; t < TILES; ++t) wr[u][t] = __builtin_nontemporal_load((const u32x4_t*)(wp[t] + (size_t)(j + NW * u) * 1024));
+                xf[u][0] = xload((size_t)(2 * (j + NW * u)));
+                xf[u][1] = xload((size_t)(2 * (j + NW * u) + 1));
             }
             __builtin_amdgcn_sched_barrier(0);      // every load of the batch is in flight before the first use (hipcc otherwise sinks
                                                     // each load to its MFMA to save registers and waits vmcnt(0) per k-block)
@@ -340,16 +402,16 @@ __global__ __launch_bounds__(512) void gemv_mfma_kernel(GemvArgs p) {
             typename T::v8 xf[U - 1][2];
 #pragma unroll
             for (int u = 0; u < U - 1; ++u) {
-                const int jj = min(j + 8 * u, j_end - 1);
+                const int jj = min(j + NW * u, j_end - 1);
 #pragma unroll
                 for (int t = 0; t < TILES; ++t) wr[u][t] = __builtin_nontemporal_load((const u32x4_t*)(wp[t] + (size_t)jj * 1024));
-                xf[u][0] = *(const typename T::v8*)(xp + (size_t)(2 * jj) * 64);
-                xf[u][1] = *(const typename T::v8*)(xp + (size_t)(2 * jj + 1) * 64);
+                xf[u][0] = xload((size_t)(2 * jj));
+                xf[u][1] = xload((size_t)(2 * jj + 1));
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < U - 1; ++u) {
-                const bool live = j + 8 * u < j_end;
+                const bool live = j + NW * u < j_end;
                 const typename T::v8 z = {};
 #pragma unroll
                 for (int t = 0; t < TILES; ++t) {
@@ -359,7 +421,7 @@ __global__ __launch_bounds__(512) void gemv_mfma_kernel(GemvArgs p) {
             }
         }
     } else {
-        // Same k order as the fp8 branch (wave w takes the 64-column groups w, w+8, ...; inside a group the two 32-blocks in order), so
+        // Same k order as the fp8 branch (wave w takes the 64-column groups w, w+NW, ...; inside a group the two 32-blocks in order), so
         // the two kernels accumulate identically and the fp8 path is bit-equal to the 16-bit path on the dequantised matrix.
         const char* wp[TILES];
 #pragma unroll
@@ -368,16 +430,16 @@ __global__ __launch_bounds__(512) void gemv_mfma_kernel(GemvArgs p) {
         const int kb_end = min(kblocks, (int)(blockIdx.y + 1) * p.kb_per);       // 32-blocks; kb_per is even
         const int j_end = (kb_end + 1) >> 1;                                     // 64-groups (the last may hold one 32-block)
         int j = ((blockIdx.y * p.kb_per) >> 1) + w;
-        for (; j + 8 * (U - 1) < j_end && 2 * (j + 8 * (U - 1)) + 1 < kb_end; j += 8 * U) {
+        for (; j + NW * (U - 1) < j_end && 2 * (j + NW * (U - 1)) + 1 < kb_end; j += NW * U) {
             typename T::v8 wf[U][2][TILES], xf[U][2];
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const size_t kb = (size_t)(2 * (j + 8 * u) + h);
+                    const size_t kb = (size_t)(2 * (j + NW * u) + h);
 #pragma unroll
                     for (int t = 0; t < TILES; ++t) wf[u][h][t] = __builtin_nontemporal_load((const typename T::v8*)(wp[t] + kb * 1024));
-                    xf[u][h] = *(const typename T::v8*)(xp + kb * 64);
+                    xf[u][h] = xload(kb);
                 }
             __builtin_amdgcn_sched_barrier(0);      // as above: the whole batch in flight before the first MFMA
 #pragma unroll
@@ -394,17 +456,17 @@ __global__ __launch_bounds__(512) void gemv_mfma_kernel(GemvArgs p) {
             for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const size_t kb = (size_t)min(2 * (j + 8 * u) + h, kb_end - 1);
+                    const size_t kb = (size_t)min(2 * (j + NW * u) + h, kb_end - 1);
 #pragma unroll
                     for (int t = 0; t < TILES; ++t) wf[u][h][t] = __builtin_nontemporal_load((const typename T::v8*)(wp[t] + kb * 1024));
-                    xf[u][h] = *(const typename T::v8*)(xp + kb * 64);
+                    xf[u][h] = xload(kb);
                 }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const bool live = 2 * (j + 8 * u) + h < kb_end;
+                    const bool live = 2 * (j + NW * u) + h < kb_end;
                     const typename T::v8 z = {};
 #pragma unroll
                     for (int t = 0; t < TILES; ++t) acc[t] = T::mfma16(wf[u][h][t], live ? xf[u][h] : z, acc[t]);
@@ -413,6 +475,19 @@ __global__ __launch_bounds__(512) void gemv_mfma_kernel(GemvArgs p) {
     }
 #pragma unroll
     for (int t = 0; t < TILES; ++t) red[w][t][lane] = acc[t];
+    if (scaled) {
+        const int n4 = p.nparts_in * 4;
+        f32x4_t ssq_acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < SSQ_LD; ++q)
+            if (tid + q * NW * 64 < n4) ssq_acc += ssq_ld[q];
+        // lanes with equal (lane & 3) hold the same 4 batch columns (NW * 64 is a multiple of 4): fold the wave, lanes 0..3 publish
+#pragma unroll
+        for (int o = 4; o <= 32; o <<= 1)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ssq_acc[e] += __shfl_xor(ssq_acc[e], o, 64);
+        if (lane < 4) ssq_red[w][lane] = ssq_acc;
+    }
     __syncthreads();
     if (w != 0) return;
     f32x4_t tot[TILES];
@@ -420,7 +495,7 @@ __global__ __launch_bounds__(512) void gemv_mfma_kernel(GemvArgs p) {
     for (int t = 0; t < TILES; ++t) {
         tot[t] = red[0][t][lane];
 #pragma unroll
-        for (int ww = 1; ww < 8; ++ww) tot[t] += red[ww][t][lane];
+        for (int ww = 1; ww < NW; ++ww) tot[t] += red[ww][t][lane];
     }
     if constexpr (W8) {                                           // per-row power-of-two scale: exact in fp32
 #pragma unroll
@@ -428,8 +503,45 @@ __global__ __launch_bounds__(512) void gemv_mfma_kernel(GemvArgs p) {
     }
     // lane holds D[n = kg*4 + r][b = l15]
     const int b = l15;
-    if (b >= p.B) return;
+    if (scaled) {
+        float ss = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) ss += ssq_red[ww][b >> 2][b & 3];       // fixed order: deterministic
+        const float rstd = rsqrtf(ss * p.inv_h + p.eps);
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) tot[t] *= rstd;
+    }
     const int n0 = blockIdx.x * 16 + kg * 4;
+    if constexpr (MODE == GV_RESIDNORM) {
+        // r = resid + y (fp32, written back); xg = round16(r * gamma); sum of r^2 over this workgroup's 16 rows per batch column
+        float sq = 0.f;
+        if (b < p.B) {
+            f32x4_t* rp = (f32x4_t*)(p.out + ((size_t)b * p.ldo + n0) * 4);
+            const f32x4_t r = r_old + tot[0];
+            *rp = r;
+            const f32x4_t g = g_nx;
+            *(u32x2_t*)(p.xg + ((size_t)b * p.ldo + n0) * 2) = pack4<T>(r[0] * g[0], r[1] * g[1], r[2] * g[2], r[3] * g[3]);
+            sq = (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
+        }
+        sq += __shfl_xor(sq, 16, 64);
+        sq += __shfl_xor(sq, 32, 64);
+        if (kg == 0) p.ssq_out[(size_t)blockIdx.x * 16 + b] = sq;               // columns >= B carry 0
+        return;
+    }
+    if constexpr (MODE == GV_F32) {
+        if (p.amax_val != nullptr) {                              // wave-uniform
+            float bv = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float v = tot[0][r]; if (n0 + r < p.N && v > bv) { bv = v; bi = n0 + r; } }      // ascending n: the first maximum wins, NaN never does
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) {
+                const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            }
+            if (kg == 0) { p.amax_val[(size_t)blockIdx.x * 16 + b] = bv; p.amax_idx[(size_t)blockIdx.x * 16 + b] = bi; }
+        }
+    }
+    if (b >= p.B) return;
     if constexpr (MODE == GV_SWIGLU) {
         float v[4];
 #pragma unroll
@@ -450,53 +562,51 @@ __global__ __launch_bounds__(512) void gemv_mfma_kernel(GemvArgs p) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// decode: residual update from split-K partials + RMSNorm in one launch (one workgroup per sequence):
-//   resid[b] += part[0][b] + part[1][b] + ...   (fixed order -> deterministic),   xn[b] = rmsnorm(resid[b]) * gamma
-// Every residual-accumulating decode GEMV (o_proj, down_proj) is followed by an RMSNorm, so the split-K combine rides
-// along for free and the GEMV can use gridDim.y splits to put >= 2 workgroups on every CU.
-// ---------------------------------------------------------------------------------------------
-template <typename T, int NP>
-__global__ __launch_bounds__(256) void rms_resid_kernel(float* __restrict__ resid, const float* __restrict__ part, int B,
-                                                        const float* __restrict__ gamma, float eps, typename T::elem* __restrict__ xn, int H) {
+// decode: resid[b] = embed[tok[b]] plus the producer side of the folded RMSNorm (see GemvArgs): xg = round16(resid * gamma of layer 0's
+// input norm), ssq[0][b] = sum resid^2 (one partial per sequence).
+template <typename T>
+__global__ __launch_bounds__(256) void embed_tok_norm_kernel(const int* __restrict__ tok, const typename T::elem* __restrict__ embed, float* __restrict__ resid,
+                                                             const float* __restrict__ gamma, typename T::elem* __restrict__ xg, float* __restrict__ ssq, int H) {
     __shared__ float red[4];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    float* r = resid + (size_t)b * H;
-    constexpr int MAXV = 5;                              // H <= 5120
-    f32x4_t v[MAXV], g[MAXV], pp[MAXV][NP > 0 ? NP : 1];
-    // issue every load up front (one L2 round trip instead of three)
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c = (i * 256 + tid) * 4;
-        if (c < H) {
-            v[i] = *(const f32x4_t*)(r + c);
-#pragma unroll
-            for (int s = 0; s < NP; ++s) pp[i][s] = *(const f32x4_t*)(part + ((size_t)s * B + b) * H + c);
-            g[i] = *(const f32x4_t*)(gamma + c);
-        }
-    }
+    const int b = blockIdx.x;
+    const typename T::elem* p = embed + (size_t)tok[b] * H;
     float ss = 0.f;
+    for (int c = threadIdx.x * 8; c < H; c += 256 * 8) {
+        const typename T::v8 v = *(const typename T::v8*)(p + c);
+        f32x4_t a, bb;
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c = (i * 256 + tid) * 4;
-        if (c < H) {
+        for (int e = 0; e < 4; ++e) { a[e] = (float)v[e]; bb[e] = (float)v[4 + e]; }
+        *(f32x4_t*)(resid + (size_t)b * H + c) = a;
+        *(f32x4_t*)(resid + (size_t)b * H + c + 4) = bb;
+        const f32x4_t g0 = *(const f32x4_t*)(gamma + c), g1 = *(const f32x4_t*)(gamma + c + 4);
+        *(u32x2_t*)((char*)xg + ((size_t)b * H + c) * 2) = pack4<T>(a[0] * g0[0], a[1] * g0[1], a[2] * g0[2], a[3] * g0[3]);
+        *(u32x2_t*)((char*)xg + ((size_t)b * H + c + 4) * 2) = pack4<T>(bb[0] * g1[0], bb[1] * g1[1], bb[2] * g1[2], bb[3] * g1[3]);
 #pragma unroll
-            for (int s = 0; s < NP; ++s) v[i] += pp[i][s];
-            if (NP > 0) *(f32x4_t*)(r + c) = v[i];
-            ss += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
-        }
+        for (int e = 0; e < 4; ++e) ss += a[e] * a[e] + bb[e] * bb[e];
     }
     ss = wave_sum(ss);
-    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
     __syncthreads();
-    const float tot = (red[0] + red[1]) + (red[2] + red[3]);
-    const float rstd = rsqrtf(tot / (float)H + eps);
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-        const int c = (i * 256 + tid) * 4;
-        if (c < H)
-            *(u32x2_t*)((char*)xn + ((size_t)b * H + c) * 2) = pack4<T>(v[i][0] * rstd * g[i][0], v[i][1] * rstd * g[i][1], v[i][2] * rstd * g[i][2], v[i][3] * rstd * g[i][3]);
+    if (threadIdx.x == 0) ssq[b] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// Producer side of the folded RMSNorm for rows that already sit in the fp32 residual (the last prompt position of every sequence
+// before lm_head): xg = round16(resid * gamma), ssq[b] = sum resid^2.  One workgroup per row.
+template <typename T>
+__global__ __launch_bounds__(256) void resid_norm_prep_kernel(const float* __restrict__ resid, const float* __restrict__ gamma, typename T::elem* __restrict__ xg,
+                                                              float* __restrict__ ssq, int H) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    float ss = 0.f;
+    for (int c = threadIdx.x * 4; c < H; c += 256 * 4) {
+        const f32x4_t r = *(const f32x4_t*)(resid + (size_t)b * H + c), g = *(const f32x4_t*)(gamma + c);
+        *(u32x2_t*)((char*)xg + ((size_t)b * H + c) * 2) = pack4<T>(r[0] * g[0], r[1] * g[1], r[2] * g[2], r[3] * g[3]);
+        ss += (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
     }
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) ssq[b] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -509,13 +619,14 @@ __global__ __launch_bounds__(256) void rms_resid_kernel(float* __restrict__ resi
 // registers (the loop only streams keys [0, pos)), so nothing waits for that store; partial states are merged inside each wave
 // with shuffles before 8 (not 64) states meet in LDS.
 // ---------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(512) void decode_attn_kernel(const typename T::elem* __restrict__ qkv, const int* __restrict__ pos_arr,
+template <typename T, int NW>
+__global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const typename T::elem* __restrict__ qkv, const int* __restrict__ pos_arr,
                                                           const float2* __restrict__ rope, typename T::elem* __restrict__ Kc,
                                                           typename T::elem* __restrict__ Vc, typename T::elem* __restrict__ out, int H, int heads,
                                                           int max_seq, float scale_log2e) {
-    __shared__ float st_m[8], st_l[8];
-    __shared__ float st_o[8][HD];
+    __shared__ float st_m[NW], st_l[NW];
+    __shared__ float st_o[NW][HD];
+    constexpr int KPR = NW * 8;                        // keys per round: NW waves x 4 slots x 2 states
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int h = blockIdx.x, b = blockIdx.y;
     const int pos = pos_arr[b];
@@ -549,8 +660,8 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(const typename T::elem
         for (int e = 0; e < 8; ++e) o[u][e] = 0.f;
     const int n_keys = pos;                            // cached keys; the fresh key (index pos) is handled from registers below
     const int key0 = w * 4 + slot;
-    // DEPTH rounds of 64 keys are kept in flight per workgroup (DEPTH x 4 x 16-B loads per lane)
-    constexpr int DEPTH = 4;
+    // DEPTH rounds of KPR keys are kept in flight per workgroup (DEPTH x 4 x 16-B loads per lane)
+    constexpr int DEPTH = NW == 8 ? 4 : 2;
     typename T::v8 kq[DEPTH][2], vq[DEPTH][2];
     auto load = [&](int key, typename T::v8& kk_, typename T::v8& vv_) {
         const int kc = max(0, min(key, n_keys - 1));   // clamped rows are masked below
@@ -572,7 +683,7 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(const typename T::elem
         }
     };
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) { load(key0 + 64 * d, kq[d][0], vq[d][0]); load(key0 + 64 * d + 32, kq[d][1], vq[d][1]); }
+    for (int d = 0; d < DEPTH; ++d) { load(key0 + KPR * d, kq[d][0], vq[d][0]); load(key0 + KPR * d + KPR / 2, kq[d][1], vq[d][1]); }
 
     // fresh token (overlaps the first loads): wave 0 appends the rotated k and v to the cache; its slot-0 lanes also keep them for the softmax
     typename T::v8 knew, vnew;
@@ -588,14 +699,14 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(const typename T::elem
         }
     }
 
-    for (int base = key0; base < n_keys; base += 64 * DEPTH) {
+    for (int base = key0; base < n_keys; base += KPR * DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) update(u, kq[d][u], vq[d][u], base + 64 * d + 32 * u < n_keys);
+            for (int u = 0; u < 2; ++u) update(u, kq[d][u], vq[d][u], base + KPR * d + (KPR / 2) * u < n_keys);
             // refill this ring slot with the round DEPTH ahead (clamped loads past the end are harmless and masked)
-            load(base + 64 * (d + DEPTH), kq[d][0], vq[d][0]);
-            load(base + 64 * (d + DEPTH) + 32, kq[d][1], vq[d][1]);
+            load(base + KPR * (d + DEPTH), kq[d][0], vq[d][0]);
+            load(base + KPR * (d + DEPTH) + KPR / 2, kq[d][1], vq[d][1]);
         }
     }
     if (w == 0) update(0, knew, vnew, slot == 0);      // the fresh key, once (wave 0, slot 0)
@@ -626,10 +737,10 @@ __global__ __launch_bounds__(512) void decode_attn_kernel(const typename T::elem
     if (tid < HD) {
         float M = st_m[0];
 #pragma unroll
-        for (int i = 1; i < 8; ++i) M = fmaxf(M, st_m[i]);
+        for (int i = 1; i < NW; ++i) M = fmaxf(M, st_m[i]);
         float L = 0.f, acc = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NW; ++i) {
             const float f = exp2f(st_m[i] - M);
             L += st_l[i] * f;
             acc += st_o[i][tid] * f;
@@ -678,6 +789,44 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ 
     }
 }
 
+
+// greedy pick from the lm_head GEMV's per-workgroup candidates (GemvArgs::amax_*): same result as argmax_kernel on the full logits
+// (largest value, smallest index on ties, NaN never), 16x fewer values to scan.
+__global__ __launch_bounds__(256) void argmax_parts_kernel(const float* __restrict__ val, const int* __restrict__ idx, int nblk, int V, int* __restrict__ next,
+                                                           int* __restrict__ pos, int* __restrict__ step, int* __restrict__ hist, int hist_stride,
+                                                           int* __restrict__ done, int eos, int advance) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid; i < nblk; i += 256) {
+        const float v = val[(size_t)i * 16 + b];
+        const int j = idx[(size_t)i * 16 + b];
+        if (v > best || (v == best && j < bi)) { best = v; bi = j; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ov = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if ((tid & 63) == 0) { sv[tid >> 6] = best; si[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int i = 1; i < 4; ++i)
+            if (sv[i] > best || (sv[i] == best && si[i] < bi)) { best = sv[i]; bi = si[i]; }
+        int tok = bi < V ? bi : 0;
+        if (advance) {
+            if (done[b]) tok = eos;
+            else if (eos >= 0 && tok == eos) done[b] = 1;
+            hist[(size_t)b * hist_stride + step[b]] = tok;
+            step[b] += 1;
+            pos[b] += 1;
+        }
+        next[b] = tok;
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 // Sampling pick (the reference's default decode mode, video_chatgpt/inference.py:106-112: do_sample=True, temperature=0.2; HF's
@@ -869,22 +1018,34 @@ int pgv_launch_prefill_attn(pgv_ctx* ctx, int dtype, const void* qkv, void* out,
     return PGV_OK;
 }
 
-int pgv_launch_rms_resid(int dtype, float* resid, const float* part, int nparts, int B, const float* gamma, float eps, void* xn, int H, hipStream_t s) {
-    PGV_CHECK(H % 4 == 0 && H <= 5120, "rms_resid: hidden %d unsupported", H);
-    if (nparts == 0) PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((rms_resid_kernel<T, 0>), dim3(B), dim3(256), 0, s, resid, part, B, gamma, eps, (typename T::elem*)xn, H));
-    else if (nparts == 2) PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((rms_resid_kernel<T, 2>), dim3(B), dim3(256), 0, s, resid, part, B, gamma, eps, (typename T::elem*)xn, H));
-    else { pgv_set_error("rms_resid: %d partials unsupported", nparts); return PGV_EINVAL; }
+int pgv_launch_final_prep(int dtype, const float* resid, const float* gamma, void* xg, float* ssq, int B, int H, hipStream_t s) {
+    PGV_CHECK(H % 4 == 0, "final_prep: hidden %d unsupported", H);
+    PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((resid_norm_prep_kernel<T>), dim3(B), dim3(256), 0, s, resid, gamma, (typename T::elem*)xg, ssq, H));
+    return PGV_OK;
+}
+
+int pgv_launch_embed_tok_norm(int dtype, const int* tok, const void* embed, float* resid, const float* gamma, void* xg, float* ssq, int B, int H, hipStream_t s) {
+    PGV_CHECK(H % 8 == 0, "embed: hidden must be a multiple of 8");
+    PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((embed_tok_norm_kernel<T>), dim3(B), dim3(256), 0, s, tok, (const typename T::elem*)embed, resid, gamma,
+                                                    (typename T::elem*)xg, ssq, H));
     return PGV_OK;
 }
 
 int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void* x, int ldx, void* out, int ldo, int N, int K, int B, hipStream_t s,
-                    int splits, const float* wscale) {
+                    int splits, const float* wscale, const GemvNorm* norm) {
     PGV_CHECK(B >= 1 && B <= 16, "gemv: batch %d outside [1,16]", B);
     PGV_CHECK(K % 32 == 0, "gemv: K=%d must be a multiple of 32", K);
     const bool w8 = wscale != nullptr;                  // W is the fp8 blocked copy (fp8.hip) with per-row scales
     GemvArgs a;
     a.W = (const char*)W; a.x = (const char*)x; a.out = (char*)out; a.N = N; a.K = K; a.B = B; a.ldx = ldx; a.ldo = ldo; a.wscale = wscale;
+    a.ssq_in = nullptr; a.nparts_in = 0; a.inv_h = 0.f; a.eps = 0.f; a.gamma = nullptr; a.xg = nullptr; a.ssq_out = nullptr; a.amax_val = nullptr; a.amax_idx = nullptr;
+    if (norm) {
+        a.ssq_in = norm->ssq_in; a.nparts_in = norm->nparts_in; a.inv_h = 1.0f / (float)norm->hidden; a.eps = norm->eps;
+        a.gamma = norm->gamma; a.xg = (char*)norm->xg; a.ssq_out = norm->ssq_out; a.amax_val = norm->amax_val; a.amax_idx = norm->amax_idx;
+        PGV_CHECK(norm->nparts_in * 4 <= 3 * 8 * 64, "gemv: %d sum-of-squares partials exceed what a consumer workgroup loads (hidden <= 6144)", norm->nparts_in);
+    }
     PGV_CHECK(splits >= 1 && (splits == 1 || mode == GV_PART), "gemv: split-K needs the partial-output mode");
+    PGV_CHECK(mode != GV_RESIDNORM || (a.gamma && a.xg && a.ssq_out), "gemv: the residual+norm producer needs gamma / xg / ssq_out");
     a.kb_per = ((((K / 32) + splits - 1) / splits) + 1) & ~1;      // 32-blocks per split, even: splits fall on 64-column boundaries
     if (w8) PGV_CHECK(K % 64 == 0, "gemv fp8: K=%d must be a multiple of 64", K);
     int grid;
@@ -892,14 +1053,15 @@ int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void
     if (mode == GV_SWIGLU) { PGV_CHECK(N % 64 == 0, "gemv swiglu: N=%d must be a multiple of 64", N); grid = N / 32; }
     else { if (mode != GV_F32) PGV_CHECK(N % 16 == 0, "gemv: N=%d must be a multiple of 16", N); grid = (N + 15) / 16; }
     pgv_prof_begin(ctx, 3, s);
-#define PGV_GEMV(MODE_, W8_) PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gemv_mfma_kernel<T, MODE_, W8_>), dim3(grid, splits), dim3(512), 0, s, a))
-#define PGV_GEMV2(MODE_) do { if (w8) PGV_GEMV(MODE_, true); else PGV_GEMV(MODE_, false); } while (0)
+#define PGV_GEMV(MODE_, W8_, NW_) PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gemv_mfma_kernel<T, MODE_, W8_, NW_>), dim3(grid, splits), dim3(NW_ * 64), 0, s, a))
+#define PGV_GEMV2(MODE_, NW_) do { if (w8) PGV_GEMV(MODE_, true, NW_); else PGV_GEMV(MODE_, false, NW_); } while (0)
     switch (mode) {
-        case GV_STORE16: PGV_GEMV2(GV_STORE16); break;
-        case GV_RESID: PGV_GEMV2(GV_RESID); break;
-        case GV_SWIGLU: PGV_GEMV2(GV_SWIGLU); break;
-        case GV_F32: PGV_GEMV2(GV_F32); break;
-        case GV_PART: PGV_GEMV2(GV_PART); break;
+        case GV_STORE16: PGV_GEMV2(GV_STORE16, 8); break;
+        case GV_RESID: PGV_GEMV2(GV_RESID, 8); break;
+        case GV_SWIGLU: PGV_GEMV2(GV_SWIGLU, 8); break;
+        case GV_F32: PGV_GEMV2(GV_F32, 8); break;
+        case GV_PART: PGV_GEMV2(GV_PART, 8); break;
+        case GV_RESIDNORM: PGV_GEMV2(GV_RESIDNORM, 16); break;
         default: pgv_set_error("gemv: bad mode %d", mode); return PGV_EINVAL;
     }
 #undef PGV_GEMV2
@@ -911,10 +1073,17 @@ int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void
 int pgv_launch_decode_attn(pgv_ctx* ctx, int dtype, const void* qkv, const int* pos, const void* rope, void* Kc, void* Vc, void* out, int B, int H,
                            int heads, int max_seq, double bytes, hipStream_t s) {
     const float sc = 0.08838834764831845f * 1.4426950408889634f;
+    static int nw = -1;
+    if (nw < 0) { const char* e = getenv("PGV_DATTN_WAVES"); nw = (e && atoi(e) == 16) ? 16 : 8; }
     pgv_prof_begin(ctx, 4, s);
-    PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((decode_attn_kernel<T>), dim3(heads, B), dim3(512), 0, s, (const typename T::elem*)qkv, pos,
-                                                    (const float2*)rope, (typename T::elem*)Kc, (typename T::elem*)Vc, (typename T::elem*)out, H, heads,
-                                                    max_seq, sc));
+    if (nw == 16)
+        PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((decode_attn_kernel<T, 16>), dim3(heads, B), dim3(1024), 0, s, (const typename T::elem*)qkv, pos,
+                                                        (const float2*)rope, (typename T::elem*)Kc, (typename T::elem*)Vc, (typename T::elem*)out, H, heads,
+                                                        max_seq, sc));
+    else
+        PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((decode_attn_kernel<T, 8>), dim3(heads, B), dim3(512), 0, s, (const typename T::elem*)qkv, pos,
+                                                        (const float2*)rope, (typename T::elem*)Kc, (typename T::elem*)Vc, (typename T::elem*)out, H, heads,
+                                                        max_seq, sc));
     pgv_prof_end(ctx, 4, s, 0.0, bytes);
     return PGV_OK;
 }
@@ -922,6 +1091,12 @@ int pgv_launch_decode_attn(pgv_ctx* ctx, int dtype, const void* qkv, const int* 
 int pgv_launch_argmax(const float* logits, int V, int B, int* next, int* pos, int* step, int* hist, int hist_stride, int* done, int eos, int advance,
                       hipStream_t s) {
     hipLaunchKernelGGL(argmax_kernel, dim3(B), dim3(1024), 0, s, logits, V, next, pos, step, hist, hist_stride, done, eos, advance);
+    return PGV_OK;
+}
+
+int pgv_launch_argmax_parts(const float* val, const int* idx, int nblk, int V, int B, int* next, int* pos, int* step, int* hist, int hist_stride, int* done,
+                            int eos, int advance, hipStream_t s) {
+    hipLaunchKernelGGL(argmax_parts_kernel, dim3(B), dim3(256), 0, s, val, idx, nblk, V, next, pos, step, hist, hist_stride, done, eos, advance);
     return PGV_OK;
 }
 
@@ -948,7 +1123,7 @@ extern "C" int pgv_gemv(pgv_ctx* ctx, int dtype, int mode, const void* d_W, cons
                         void* stream) {
     PGV_CHECK(ctx && d_W && d_x && d_out, "pgv_gemv: null argument");
     PGV_CHECK(mode >= 0 && mode <= 3, "pgv_gemv: mode %d outside [0,3]", mode);
-    return pgv_launch_gemv(ctx, dtype, mode, d_W, d_x, ldx, d_out, ldo, N, K, B, (hipStream_t)stream, 1, nullptr);
+    return pgv_launch_gemv(ctx, dtype, mode, d_W, d_x, ldx, d_out, ldo, N, K, B, (hipStream_t)stream, 1, nullptr, nullptr);
 }
 
 #include "weights.h"
@@ -963,5 +1138,5 @@ extern "C" int pgv_gemv_fp8(pgv_ctx* ctx, int dtype, int mode, const void* d_W8,
                             int K, int B, void* stream) {
     PGV_CHECK(ctx && d_W8 && d_scales && d_x && d_out, "pgv_gemv_fp8: null argument");
     PGV_CHECK(mode >= GV_STORE16 && mode <= GV_F32, "pgv_gemv_fp8: mode %d outside [0,3]", mode);
-    return pgv_launch_gemv(ctx, dtype, mode, d_W8, d_x, ldx, d_out, ldo, N, K, B, (hipStream_t)stream, 1, d_scales);
+    return pgv_launch_gemv(ctx, dtype, mode, d_W8, d_x, ldx, d_out, ldo, N, K, B, (hipStream_t)stream, 1, d_scales, nullptr);
 }

@@ -164,3 +164,11 @@ struct GemmArgs {
     bool w_blocked = false;       // W in the fragment-blocked layout (weights.h) -- the decoder's packed weights
 };
 int pgv_launch_gemm(pgv_ctx* ctx, int dtype, const GemmArgs& a, hipStream_t s);
+
+// Folded-RMSNorm arguments of the decode GEMVs (llm_kernels.hip, GemvArgs).  Consumer modes (store16 / swiglu / f32): ssq_in [nparts_in][16]
+// + hidden + eps (null ssq_in = plain GEMV).  Producer mode (residual + norm): out = fp32 residual, gamma / xg / ssq_out.
+struct GemvNorm {
+    const float* ssq_in = nullptr; int nparts_in = 0; int hidden = 1; float eps = 0.f;
+    const float* gamma = nullptr; void* xg = nullptr; float* ssq_out = nullptr;
+    float* amax_val = nullptr; int* amax_idx = nullptr;      // f32 mode: per-workgroup greedy candidates [ceil(N / 16)][16]
+};
