@@ -68,11 +68,14 @@ int launch_norm(const float* x, const float* g, const float* b, float eps, void*
 // pre_layrnorm :642): row (t, n) = (n == 0 ? class_embedding : patch_embed[t, n-1]) + position[n], LayerNorm'ed
 // -> fp32 residual stream (= hidden_states[0]).
 // ---------------------------------------------------------------------------------------------
-template <int NV>
+// When `gnext` is given (the tower runs at least one layer) the kernel is also the first PRODUCER of the folded LayerNorm (gemm.hip, EPI_LN_*):
+// x16 = round16(out * gnext) and rowstat = (mean, rstd) of the OUTPUT row, so layer 0's qkv GEMM needs no LayerNorm launch.
+template <typename T, int NV>
 __global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__ pe, const float* __restrict__ cls,
                                                        const float* __restrict__ pos, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, float* __restrict__ out,
-                                                       int rows, int tokens) {
+                                                       int rows, int tokens, const float* __restrict__ gnext, char* __restrict__ x16,
+                                                       float* __restrict__ rowstat) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -95,6 +98,7 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__
         for (int e = 0; e < 4; ++e) { float d = v[i][e] - mean; ss += d * d; }
     const float rstd = rsqrtf(wave_sum(ss) * (1.0f / cols) + eps);
     f32x4_t* o = (f32x4_t*)(out + (size_t)row * cols);
+    float s1 = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const f32x4_t g = ((const f32x4_t*)gamma)[i * 64 + lane], b = ((const f32x4_t*)beta)[i * 64 + lane];
@@ -102,7 +106,55 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__
 #pragma unroll
         for (int e = 0; e < 4; ++e) r[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
         o[i * 64 + lane] = r;
+        v[i] = r;
+        s1 += (r[0] + r[1]) + (r[2] + r[3]);
     }
+    if (gnext == nullptr) return;
+    const float m2 = wave_sum(s1) * (1.0f / cols);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[i][e] - m2; q += d * d; }
+    const float rstd2 = rsqrtf(wave_sum(q) * (1.0f / cols) + eps);
+    if (lane == 0) *(f32x2_t*)(rowstat + (size_t)row * 2) = f32x2_t{m2, rstd2};
+    u32x2_t* xr = (u32x2_t*)(x16 + (size_t)row * cols * 2);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const f32x4_t g = ((const f32x4_t*)gnext)[i * 64 + lane];
+        xr[i * 64 + lane] = pack4<T>(v[i][0] * g[0], v[i][1] * g[1], v[i][2] * g[2], v[i][3] * g[3]);
+    }
+}
+
+// Folded LayerNorm, between producer and consumer: per-row partial (sum, sum of squares) over NP 64-column pieces ([NP][rows][2]) -> (mean, rstd).
+// var = E[x^2] - mean^2 in fp32 (the CLIP residual's row mean is small against its spread; the two-pass form would need the row again).
+__global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__ part, float* __restrict__ rowstat, int rows, int np, float inv_cols, float eps) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    const f32x2_t* p = (const f32x2_t*)part + row;               // piece-major [np][rows][2]: coalesced across the rows of a wave
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = 0; i < np; ++i) { const f32x2_t v = p[(size_t)i * rows]; s1 += v[0]; s2 += v[1]; }
+    const float mean = s1 * inv_cols;
+    const float var = fmaxf(s2 * inv_cols - mean * mean, 0.f);
+    *(f32x2_t*)(rowstat + (size_t)row * 2) = f32x2_t{mean, rsqrtf(var + eps)};
+}
+
+// Folded LayerNorm, load time: for a consumer weight W [N, K] (row-major 16-bit) with bias b and the LayerNorm parameters (gamma, beta) in front of it:
+//   colsum[n] = sum_k gamma_k W[n,k],   bias2[n] = b[n] + sum_k beta_k W[n,k]      (fp32).  One wave per output row.
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fold_kernel(const typename T::elem* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float* __restrict__ colsum, float* __restrict__ bias2, int N, int K) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float sg = 0.f, sb = 0.f;
+    for (int k = lane * 8; k < K; k += 64 * 8) {
+        const typename T::v8 w = *(const typename T::v8*)(W + (size_t)n * K + k);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sg += (float)w[e] * gamma[k + e]; sb += (float)w[e] * beta[k + e]; }
+    }
+    sg = wave_sum(sg); sb = wave_sum(sb);
+    if (lane == 0) { colsum[n] = sg; bias2[n] = bias[n] + sb; }
 }
 
 // fp32 -> 16-bit cast, 4 elements per thread
@@ -226,10 +278,21 @@ int pgv_launch_rmsnorm(int dtype, const float* x, const float* g, float eps, voi
     PGV_DISPATCH_DTYPE(dtype, T, return (launch_norm<T, true>(x, g, nullptr, eps, y, rows, cols, s)));
     return PGV_OK;
 }
-int pgv_launch_embed_ln(const float* pe, const float* cls, const float* pos, const float* g, const float* b, float eps, float* out,
-                        int rows, int tokens, int cols, hipStream_t s) {
+int pgv_launch_embed_ln(int dtype, const float* pe, const float* cls, const float* pos, const float* g, const float* b, float eps, float* out,
+                        int rows, int tokens, int cols, const float* gnext, void* x16, float* rowstat, hipStream_t s) {
     PGV_CHECK(cols == 1024, "embed_ln: CLIP width must be 1024 (got %d)", cols);
-    hipLaunchKernelGGL((embed_ln_kernel<4>), dim3((rows + 3) / 4), dim3(256), 0, s, pe, cls, pos, g, b, eps, out, rows, tokens);
+    PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((embed_ln_kernel<T, 4>), dim3((rows + 3) / 4), dim3(256), 0, s, pe, cls, pos, g, b, eps, out, rows, tokens,
+                                                    gnext, (char*)x16, rowstat));
+    return PGV_OK;
+}
+int pgv_launch_ln_stats(const float* part, float* rowstat, int rows, int np, int cols, float eps, hipStream_t s) {
+    hipLaunchKernelGGL(ln_stats_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, part, rowstat, rows, np, 1.0f / (float)cols, eps);
+    return PGV_OK;
+}
+int pgv_launch_ln_fold(int dtype, const void* W, const float* bias, const float* gamma, const float* beta, float* colsum, float* bias2, int N, int K, hipStream_t s) {
+    PGV_CHECK(K % 512 == 0, "ln_fold: K=%d must be a multiple of 512", K);
+    PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((ln_fold_kernel<T>), dim3((N + 3) / 4), dim3(256), 0, s, (const typename T::elem*)W, bias, gamma, beta, colsum,
+                                                    bias2, N, K));
     return PGV_OK;
 }
 int pgv_launch_cast(int dtype, const float* x, void* y, size_t n, hipStream_t s) {

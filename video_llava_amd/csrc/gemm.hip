@@ -27,7 +27,32 @@ struct KArgs {
     int M, N, K;            // logical sizes (N = output columns before SWIGLU halving)
     int ntm, ntn;
     int wblk;               // W is in the fragment-blocked layout (weights.h) instead of row-major
+    // LayerNorm folded into the GEMMs around it (CLIP tower; see the EPI_LN_* epilogues)
+    const float* rowstat;   // consumer: [M][2] = (mean, rstd) of the residual row
+    const float* colsum;    // consumer: [N] s_n = sum_k gamma_k W[n,k]
+    const float* gnext;     // producer: [N] gamma of the LayerNorm that follows
+    char* x16; int ldx16;   // producer: 16-bit copy round16(resid * gnext), row stride ldx16 elements
+    float* stats_part;      // producer: [N/64][M][2] partial (sum, sum of squares) of the new residual row over each 64-column piece
 };
+
+// Internal epilogues of the CLIP tower (not part of the public pgv_epi enum).  LayerNorm has no launch of its own:
+//   LN(x) W^T + b = rstd (x gamma) W^T - rstd mu (W gamma) + (b + W beta)
+// The GEMM that COMPLETES a residual row block (out_proj, fc2; EPI_BIAS_RESID_LNOUT) writes, next to the fp32 residual, the 16-bit operand
+// x16 = round16(resid * gamma_next) of the next GEMM and per-row partial sums (sum, sum of squares) over 64-column pieces; a small kernel
+// turns the partials into (mean, rstd) per row; the consumer GEMM (qkv, fc1; EPI_LN_BIAS / EPI_LN_BIAS_QGELU) finishes in its epilogue:
+//   out[m,n] = rstd_m (acc[m,n] - mean_m s_n) + b'_n,   s_n = sum_k gamma_k W[n,k],  b'_n = b_n + sum_k beta_k W[n,k]  (fp32, at load time).
+// No weight is modified (gamma rides on the activation side), the statistics come from the fp32 residual; the 16-bit rounding moves from
+// after the normalisation to before it (same relative size).  Saves the read of the fp32 residual + the launch of every LayerNorm.
+enum { EPI_LN_BIAS = 8, EPI_LN_BIAS_QGELU = 9, EPI_BIAS_RESID_LNOUT = 10 };
+
+// sum over each aligned group of 16 lanes (DPP: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_ror:4, row_ror:8)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
+    return v;
+}
 
 // x * sigmoid(a x) as v_mul, v_exp, v_add, v_rcp, v_mul.  The IEEE division `x / (1 + expf(..))` expands to ~10 more VALU per element
 // (div_scale / fma chain / div_fixup): SQ_INSTS_VALU per MFMA was 5.2 in the fc1 GEMM against 1.8 with the plain bias epilogue.
@@ -86,17 +111,34 @@ __device__ __forceinline__ void epilogue_w4(const KArgs& p, f32x16_t (&acc)[4][4
     // beyond M fall outside the buffer descriptor, columns beyond N get an out-of-range voffset.
     const int l31 = lane & 31, hi = lane >> 5;
     const int rrow = lane >> 4, rc = lane & 15;                // read side: 4 rows x 16 chunks of 16 B per instruction
-    constexpr bool OUT32 = (EPI == PGV_EPI_RESID || EPI == PGV_EPI_BIAS_RESID || EPI == PGV_EPI_F32);
-    constexpr bool RMW = (EPI == PGV_EPI_RESID || EPI == PGV_EPI_BIAS_RESID);
+    constexpr bool OUT32 = (EPI == PGV_EPI_RESID || EPI == PGV_EPI_BIAS_RESID || EPI == PGV_EPI_F32 || EPI == EPI_BIAS_RESID_LNOUT);
+    constexpr bool RMW = (EPI == PGV_EPI_RESID || EPI == PGV_EPI_BIAS_RESID || EPI == EPI_BIAS_RESID_LNOUT);
     constexpr bool SWIGLU = (EPI == PGV_EPI_SWIGLU);
+    constexpr bool LN_IN = (EPI == EPI_LN_BIAS || EPI == EPI_LN_BIAS_QGELU);      // consumer of the folded LayerNorm
+    constexpr bool LN_OUT = (EPI == EPI_BIAS_RESID_LNOUT);                        // producer
     constexpr int ES = OUT32 ? 4 : 2;
     const int rows_valid = max(0, min(128, p.M - m0w));
     const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(p.C + (size_t)m0w * p.ldc * ES, (unsigned)rows_valid * (unsigned)p.ldc * ES);
     const unsigned rowpitch = (unsigned)p.ldc * ES;
     unsigned voff[2];
     f32x4_t bv[2];
+    f32x4_t sv[2];                                             // LN_IN: column sums s_n;  LN_OUT: gamma of the next LayerNorm
+    unsigned voffx[2];                                         // LN_OUT: offsets into the x16 copy
+    __amdgpu_buffer_rsrc_t rs_aux, rs_aux2;                    // LN_IN: rowstat;  LN_OUT: x16 and the partial statistics
+    if constexpr (LN_IN) rs_aux = make_rsrc(p.rowstat + (size_t)m0w * 2, (unsigned)rows_valid * 8u);
+    if constexpr (LN_OUT) {
+        rs_aux = make_rsrc(p.x16 + (size_t)m0w * p.ldx16 * 2, (unsigned)rows_valid * (unsigned)p.ldx16 * 2u);
+        // partial statistics, piece-major [N/64][M][2]: the descriptor spans all pieces from this sub-tile's first row; rows >= M of the last
+        // tile row land in the next piece's first rows... so they are dropped by the row test below instead of the range check
+        rs_aux2 = make_rsrc(p.stats_part + (size_t)m0w * 2, (unsigned)(((size_t)(p.N >> 6) - 1) * p.M * 8 + (size_t)rows_valid * 8));
+    }
 #pragma unroll
     for (int jp = 0; jp < 2; ++jp) {
+        if constexpr (LN_IN || LN_OUT) {
+            const int col = n0w + jp * 64 + rc * 4;
+            sv[jp] = *(const f32x4_t*)((LN_IN ? p.colsum : p.gnext) + min(col, p.N - 4));
+            if constexpr (LN_OUT) voffx[jp] = (col < p.N) ? (unsigned)rrow * (unsigned)p.ldx16 * 2u + (unsigned)col * 2u : OOB;
+        }
         if constexpr (SWIGLU) {
             // W rows interleaved per 64 as [32 gate | 32 up]: piece jp holds 32 gate + 32 up columns -> 32 output columns;
             // lanes 0..7 of a row group own output columns 4 (rc & 7) .. +3 (rc >= 8 lanes idle on the store)
@@ -109,9 +151,17 @@ __device__ __forceinline__ void epilogue_w4(const KArgs& p, f32x16_t (&acc)[4][4
             bv[jp] = *(const f32x4_t*)(p.bias + min(col, p.N - 4));
         }
     }
+    u32x2_t rst[8];                                            // LN_IN: (mean, rstd) of the 8 rows
+    float keep1 = 0.f, keep2 = 0.f;                            // LN_OUT: (sum, sum of squares) of the row this lane reports
 #pragma unroll
     for (int piece = 0; piece < 8; ++piece) {
         const int i = piece >> 1, jp = piece & 1;
+        if constexpr (LN_IN) {
+            if (jp == 0) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) rst[r] = __builtin_amdgcn_raw_buffer_load_b64(rs_aux, (unsigned)(i * 32 + r * 4 + rrow) * 8u, 0, 0);
+            }
+        }
         u32x4_t old[8];
         if constexpr (RMW) {
 #pragma unroll
@@ -136,11 +186,22 @@ __device__ __forceinline__ void epilogue_w4(const KArgs& p, f32x16_t (&acc)[4][4
                 const f32x4_t u = *(const f32x4_t*)(stg + row * 256 + (((rc ^ 8) ^ (row & 15)) << 4));     // partner chunk: up (for rc < 8)
                 __builtin_amdgcn_raw_buffer_store_b64(pack4<T>(silu_f(d[0]) * u[0], silu_f(d[1]) * u[1], silu_f(d[2]) * u[2], silu_f(d[3]) * u[3]), rsrc, o, 0, 0);
             } else {
+                if constexpr (LN_IN) {
+                    const f32x2_t ms = __builtin_bit_cast(f32x2_t, rst[r]);            // (mean, rstd)
+                    const float a = ms[1], c = -ms[1] * ms[0];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    d[e] += bv[jp][e];
-                    if constexpr (EPI == PGV_EPI_BIAS_QGELU) d[e] = quick_gelu_f(d[e]);
-                    if constexpr (EPI == PGV_EPI_BIAS_GELU) d[e] = gelu_erf_f(d[e]);
+                    for (int e = 0; e < 4; ++e) d[e] = a * d[e] + (c * sv[jp][e] + bv[jp][e]);       // rstd (acc - mean s_n) + b'_n
+                    if constexpr (EPI == EPI_LN_BIAS_QGELU) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) d[e] = quick_gelu_f(d[e]);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        d[e] += bv[jp][e];
+                        if constexpr (EPI == PGV_EPI_BIAS_QGELU) d[e] = quick_gelu_f(d[e]);
+                        if constexpr (EPI == PGV_EPI_BIAS_GELU) d[e] = gelu_erf_f(d[e]);
+                    }
                 }
                 if constexpr (RMW) {
                     const f32x4_t q = __builtin_bit_cast(f32x4_t, old[r]);
@@ -148,7 +209,20 @@ __device__ __forceinline__ void epilogue_w4(const KArgs& p, f32x16_t (&acc)[4][4
                 }
                 if constexpr (OUT32) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, d), rsrc, o, 0, 0);
                 else __builtin_amdgcn_raw_buffer_store_b64(pack4<T>(d[0], d[1], d[2], d[3]), rsrc, o, 0, 0);
+                if constexpr (LN_OUT) {
+                    __builtin_amdgcn_raw_buffer_store_b64(pack4<T>(d[0] * sv[jp][0], d[1] * sv[jp][1], d[2] * sv[jp][2], d[3] * sv[jp][3]), rs_aux,
+                                                          voffx[jp] + (unsigned)(i * 32 + r * 4) * (unsigned)p.ldx16 * 2u, 0, 0);
+                    // the 16 lanes of a DPP row hold the 64 columns of this piece of one residual row: fold them (every lane gets the total);
+                    // lane rc == r keeps it, so after the 8 rows lane (rrow, rc < 8) owns row rc * 4 + rrow of the piece's 32
+                    const float t1 = row16_sum((d[0] + d[1]) + (d[2] + d[3])), t2 = row16_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]));
+                    if (rc == r) { keep1 = t1; keep2 = t2; }
+                }
             }
+        }
+        if constexpr (LN_OUT) {
+            // one coalesced store per piece: 32 consecutive rows x 8 bytes of the piece-major partial array [N/64][M][2]
+            const unsigned so = (rc < 8 && i * 32 + rc * 4 + rrow < rows_valid) ? (unsigned)(i * 32 + rc * 4 + rrow) * 8u : OOB;
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, f32x2_t{keep1, keep2}), rs_aux2, so, (unsigned)((n0w >> 6) + jp) * (unsigned)p.M * 8u, 0);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -383,6 +457,9 @@ int dispatch_epi(int epi, const KArgs& k, hipStream_t s, int num_cu) {
         case PGV_EPI_BIAS_RESID: return launch_w4<T, PGV_EPI_BIAS_RESID>(k, s, num_cu);
         case PGV_EPI_SWIGLU:     return launch_w4<T, PGV_EPI_SWIGLU>(k, s, num_cu);
         case PGV_EPI_F32:        return launch_w4<T, PGV_EPI_F32>(k, s, num_cu);
+        case EPI_LN_BIAS:        return launch_w4<T, EPI_LN_BIAS>(k, s, num_cu);
+        case EPI_LN_BIAS_QGELU:  return launch_w4<T, EPI_LN_BIAS_QGELU>(k, s, num_cu);
+        case EPI_BIAS_RESID_LNOUT: return launch_w4<T, EPI_BIAS_RESID_LNOUT>(k, s, num_cu);
     }
     pgv_set_error("unknown epilogue %d", epi);
     return PGV_EINVAL;
@@ -396,7 +473,9 @@ int pgv_launch_gemm(pgv_ctx* ctx, int dtype, const GemmArgs& a, hipStream_t s) {
     PGV_CHECK(a.N % 8 == 0, "gemm: N=%d must be a multiple of 8", a.N);
     PGV_CHECK(a.lda % 8 == 0 && a.ldw % 8 == 0, "gemm: lda/ldw must be multiples of 8 elements");
     PGV_CHECK(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0, "gemm: A/W must be 16-byte aligned");
-    const bool out32 = (a.epi == PGV_EPI_RESID || a.epi == PGV_EPI_BIAS_RESID || a.epi == PGV_EPI_F32);
+    const bool out32 = (a.epi == PGV_EPI_RESID || a.epi == PGV_EPI_BIAS_RESID || a.epi == PGV_EPI_F32 || a.epi == EPI_BIAS_RESID_LNOUT);
+    if (a.epi == EPI_LN_BIAS || a.epi == EPI_LN_BIAS_QGELU) PGV_CHECK(a.rowstat && a.colsum && a.bias, "gemm: the LayerNorm-consumer epilogue needs rowstat / colsum / bias");
+    if (a.epi == EPI_BIAS_RESID_LNOUT) PGV_CHECK(a.gnext && a.x16 && a.stats_part && a.N % 64 == 0 && a.ldx16 % 4 == 0, "gemm: the LayerNorm-producer epilogue needs gnext / x16 / stats_part and N %% 64 == 0");
     PGV_CHECK(((uintptr_t)a.C & (out32 ? 15 : 7)) == 0 && a.ldc % 4 == 0, "gemm: C misaligned (ptr/ldc)");
     PGV_CHECK((size_t)256 * a.lda * 2 < 0xffffffffull && (size_t)256 * a.ldw * 2 < 0xffffffffull && (size_t)128 * a.ldc * 4 < 0x7fffffffull,
               "gemm: leading dimension too large for the 32-bit buffer offsets");
@@ -405,6 +484,7 @@ int pgv_launch_gemm(pgv_ctx* ctx, int dtype, const GemmArgs& a, hipStream_t s) {
     k.lda = a.lda; k.ldw = a.ldw; k.ldc = a.ldc; k.M = a.M; k.N = a.N; k.K = a.K;
     k.ntm = 0; k.ntn = 0;
     k.wblk = a.w_blocked ? 1 : 0;
+    k.rowstat = a.rowstat; k.colsum = a.colsum; k.gnext = a.gnext; k.x16 = (char*)a.x16; k.ldx16 = a.ldx16; k.stats_part = a.stats_part;
     PGV_CHECK(!a.w_blocked || a.N % 16 == 0, "gemm: blocked weights need N %% 16 == 0");
     if (k.bias == nullptr) {        // the branch-free epilogue always reads a bias vector
         PGV_CHECK(a.N <= PGV_ZERO_BIAS_LEN, "gemm: N=%d exceeds the zero-bias vector", a.N);

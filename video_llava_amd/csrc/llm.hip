@@ -79,7 +79,7 @@ struct pgv_kv {
     int active = 0;                     // sequences of the last prefill
     // one decode step captured as a hipGraph (all kernel arguments are fixed device addresses; positions, current
     // tokens and step counters live in device memory and are advanced by the argmax kernel)
-    hipGraphExec_t gexec = nullptr;
+    hipGraphExec_t gexec[2] = {nullptr, nullptr};      // [0]: one token step, [1]: kGraphSteps consecutive steps
     int g_B = 0, g_eos = 0, g_flags = 0, g_gen = -1, g_topk = 0;
     float g_temp = 0.f;
     float* d_u = nullptr;               // uniforms of a sampled decode run: [max_seq][B], indexed by the device-side step counter
@@ -320,7 +320,7 @@ extern "C" int pgv_kv_create(pgv_ctx* ctx, pgv_llm* llm, int batch, int max_seq,
 
 extern "C" void pgv_kv_destroy(pgv_kv* kv) {
     if (!kv) return;
-    if (kv->gexec) (void)hipGraphExecDestroy(kv->gexec);
+    for (auto g : kv->gexec) if (g) (void)hipGraphExecDestroy(g);
     if (kv->blob) (void)hipFree(kv->blob);
     delete kv;
 }
@@ -471,36 +471,58 @@ static bool graphs_enabled() {
     return v == 1;
 }
 
-// One decode step: eager the first time (loads code objects), then replayed from a captured hipGraph.  Per-family
-// event timers need eager launches, so profiling disables the graph.
-static int decode_step(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int eos, int flags, hipStream_t s) {
+// Decode steps: eager the first time (loads code objects), then replayed from captured hipGraphs -- one graph holding kGraphSteps
+// consecutive token steps (positions, current tokens and step counters live in device memory and are advanced by the pick kernel, so
+// a graph is valid for any starting position) and one holding a single step for the remainder.  Per-family event timers need eager
+// launches, so profiling disables the graphs.
+constexpr int kGraphSteps = 8;
+
+static int decode_graph(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int eos, int flags, int which, int steps, hipStream_t s) {
     const int B = kv->active;
-    if (ctx->prof || !graphs_enabled() || !kv->warmed) {
-        kv->warmed = true;
-        PGV_TRY(decode_enqueue(ctx, m, kv, eos, flags, s));
-    } else {
-        if (!kv->gexec || kv->g_B != B || kv->g_eos != eos || kv->g_flags != flags || kv->g_gen != m->generation ||
-            ((flags & AM_SAMPLE) && (kv->g_temp != kv->s_temp || kv->g_topk != kv->s_topk))) {
-            if (kv->gexec) { (void)hipGraphExecDestroy(kv->gexec); kv->gexec = nullptr; }
-            // capture on a library-owned stream (the caller's may be the legacy default stream, which cannot be
-            // captured); capture executes nothing, the instantiated graph is then launched on the caller's stream
-            hipGraph_t graph = nullptr;
-            if (!ctx->cap_stream) PGV_HIP(hipStreamCreateWithFlags(&ctx->cap_stream, hipStreamNonBlocking));
-            PGV_HIP(hipStreamBeginCapture(ctx->cap_stream, hipStreamCaptureModeRelaxed));
-            const int rc = decode_enqueue(ctx, m, kv, eos, flags, ctx->cap_stream);
-            hipError_t e = hipStreamEndCapture(ctx->cap_stream, &graph);
-            if (rc != PGV_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-            if (e != hipSuccess) { pgv_set_error("decode graph capture failed: %s", hipGetErrorString(e)); return PGV_EHIP; }
-            e = hipGraphInstantiate(&kv->gexec, graph, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(graph);
-            if (e != hipSuccess) { kv->gexec = nullptr; pgv_set_error("decode graph instantiate failed: %s", hipGetErrorString(e)); return PGV_EHIP; }
-            kv->g_B = B; kv->g_eos = eos; kv->g_flags = flags; kv->g_gen = m->generation; kv->g_temp = kv->s_temp; kv->g_topk = kv->s_topk;
-        }
-        PGV_HIP(hipGraphLaunch(kv->gexec, s));
+    if (kv->g_B != B || kv->g_eos != eos || kv->g_flags != flags || kv->g_gen != m->generation ||
+        ((flags & AM_SAMPLE) && (kv->g_temp != kv->s_temp || kv->g_topk != kv->s_topk))) {
+        for (auto& g : kv->gexec) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+        kv->g_B = B; kv->g_eos = eos; kv->g_flags = flags; kv->g_gen = m->generation; kv->g_temp = kv->s_temp; kv->g_topk = kv->s_topk;
     }
-    for (int b = 0; b < B; ++b) kv->h_len[b] += 1;
+    if (!kv->gexec[which]) {
+        // capture on a library-owned stream (the caller's may be the legacy default stream, which cannot be
+        // captured); capture executes nothing, the instantiated graph is then launched on the caller's stream
+        hipGraph_t graph = nullptr;
+        if (!ctx->cap_stream) PGV_HIP(hipStreamCreateWithFlags(&ctx->cap_stream, hipStreamNonBlocking));
+        PGV_HIP(hipStreamBeginCapture(ctx->cap_stream, hipStreamCaptureModeRelaxed));
+        int rc = PGV_OK;
+        for (int i = 0; i < steps && rc == PGV_OK; ++i) rc = decode_enqueue(ctx, m, kv, eos, flags, ctx->cap_stream);
+        hipError_t e = hipStreamEndCapture(ctx->cap_stream, &graph);
+        if (rc != PGV_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+        if (e != hipSuccess) { pgv_set_error("decode graph capture failed: %s", hipGetErrorString(e)); return PGV_EHIP; }
+        e = hipGraphInstantiate(&kv->gexec[which], graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) { kv->gexec[which] = nullptr; pgv_set_error("decode graph instantiate failed: %s", hipGetErrorString(e)); return PGV_EHIP; }
+    }
+    PGV_HIP(hipGraphLaunch(kv->gexec[which], s));
     return PGV_OK;
 }
+
+static int decode_steps(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int eos, int flags, int n, hipStream_t s) {
+    const int B = kv->active;
+    while (n > 0) {
+        int k = 1;
+        if (ctx->prof || !graphs_enabled() || !kv->warmed) {
+            kv->warmed = true;
+            PGV_TRY(decode_enqueue(ctx, m, kv, eos, flags, s));
+        } else if (n >= kGraphSteps) {
+            k = kGraphSteps;
+            PGV_TRY(decode_graph(ctx, m, kv, eos, flags, 1, kGraphSteps, s));
+        } else {
+            PGV_TRY(decode_graph(ctx, m, kv, eos, flags, 0, 1, s));
+        }
+        for (int b = 0; b < B; ++b) kv->h_len[b] += k;
+        n -= k;
+    }
+    return PGV_OK;
+}
+
+static int decode_step(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int eos, int flags, hipStream_t s) { return decode_steps(ctx, m, kv, eos, flags, 1, s); }
 
 static int check_decode(pgv_llm* m, pgv_kv* kv, int steps, const char* who) {
     PGV_CHECK(m && kv && kv->llm == m, "%s: bad model / cache", who);
@@ -531,7 +553,7 @@ extern "C" int pgv_llm_decode_greedy(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, const
     const int B = kv->active;
     if (d_first != kv->d_cur) PGV_HIP(hipMemcpyAsync(kv->d_cur, d_first, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
     PGV_HIP(hipMemsetAsync(kv->d_step, 0, (size_t)kv->B * 4, s));
-    for (int i = 0; i < n; ++i) PGV_TRY(decode_step(ctx, m, kv, eos_id, AM_INC_POS | AM_RECORD, s));
+    PGV_TRY(decode_steps(ctx, m, kv, eos_id, AM_INC_POS | AM_RECORD, n, s));
     PGV_HIP(hipMemcpy2DAsync(d_tokens, (size_t)n * 4, kv->d_hist, (size_t)kv->max_seq * 4, (size_t)n * 4, B, hipMemcpyDeviceToDevice, s));
     PGV_HIP(hipGetLastError());
     return PGV_OK;
@@ -562,7 +584,7 @@ extern "C" int pgv_llm_decode_sample(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, const
     PGV_HIP(hipMemsetAsync(kv->d_step, 0, (size_t)kv->B * 4, s));
     PGV_HIP(hipMemcpyAsync(kv->d_u, d_u, (size_t)n * B * 4, hipMemcpyDeviceToDevice, s));     // n <= max_seq (check_decode)
     kv->s_temp = temperature; kv->s_topk = top_k;
-    for (int i = 0; i < n; ++i) PGV_TRY(decode_step(ctx, m, kv, eos_id, AM_INC_POS | AM_RECORD | AM_SAMPLE, s));
+    PGV_TRY(decode_steps(ctx, m, kv, eos_id, AM_INC_POS | AM_RECORD | AM_SAMPLE, n, s));
     PGV_HIP(hipMemcpy2DAsync(d_tokens, (size_t)n * 4, kv->d_hist, (size_t)kv->max_seq * 4, (size_t)n * 4, B, hipMemcpyDeviceToDevice, s));
     PGV_HIP(hipGetLastError());
     return PGV_OK;

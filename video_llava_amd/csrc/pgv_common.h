@@ -162,7 +162,11 @@ struct GemmArgs {
     int M, N, K;
     int epi;
     bool w_blocked = false;       // W in the fragment-blocked layout (weights.h) -- the decoder's packed weights
+    // folded LayerNorm (gemm.hip, EPI_LN_*): consumer side rowstat [M][2] + colsum [N]; producer side gnext [N], x16 [M][ldx16], stats_part [M][N/64][2]
+    const float* rowstat = nullptr; const float* colsum = nullptr;
+    const float* gnext = nullptr; void* x16 = nullptr; int ldx16 = 0; float* stats_part = nullptr;
 };
+enum { PGV_EPI_LN_BIAS = 8, PGV_EPI_LN_BIAS_QGELU = 9, PGV_EPI_BIAS_RESID_LNOUT = 10 };     // internal epilogues (gemm.hip)
 int pgv_launch_gemm(pgv_ctx* ctx, int dtype, const GemmArgs& a, hipStream_t s);
 
 // Folded-RMSNorm arguments of the decode GEMVs (llm_kernels.hip, GemvArgs).  Consumer modes (store16 / swiglu / f32): ssq_in [nparts_in][16]

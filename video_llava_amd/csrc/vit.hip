@@ -2,14 +2,17 @@
 // Replaces `vision_tower(image_tensor, output_hidden_states=True).hidden_states[k]`
 // (video_chatgpt/inference.py:93-94; chat.py:140-143; scripts/save_spatio_temporal_clip_features.py:116-120),
 // i.e. HF CLIPVisionTransformer (HF:clip/modeling_clip.py:594-658) up to encoder layer k.
+#include <stdlib.h>
 #include <string.h>
 
 #include "pgv_common.h"
 #include "weights.h"
 
 int pgv_launch_layernorm(int dtype, const float* x, const float* g, const float* b, float eps, void* y, int rows, int cols, hipStream_t s);
-int pgv_launch_embed_ln(const float* pe, const float* cls, const float* pos, const float* g, const float* b, float eps, float* out,
-                        int rows, int tokens, int cols, hipStream_t s);
+int pgv_launch_embed_ln(int dtype, const float* pe, const float* cls, const float* pos, const float* g, const float* b, float eps, float* out,
+                        int rows, int tokens, int cols, const float* gnext, void* x16, float* rowstat, hipStream_t s);
+int pgv_launch_ln_stats(const float* part, float* rowstat, int rows, int np, int cols, float eps, hipStream_t s);
+int pgv_launch_ln_fold(int dtype, const void* W, const float* bias, const float* gamma, const float* beta, float* colsum, float* bias2, int N, int K, hipStream_t s);
 int pgv_launch_cast(int dtype, const float* x, void* y, size_t n, hipStream_t s);
 int pgv_launch_im2col(const void* pix, void* a0, int T, int S, int g, int p, int Kp, hipStream_t s);
 int pgv_launch_vit_attn(pgv_ctx* ctx, int dtype, const void* qkv, int ld, void* out, int ldo, int T, int N, int C, int heads, hipStream_t s);
@@ -18,6 +21,9 @@ struct VitLayer {
     float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
     void *wqkv, *wo, *w1, *w2;
     float *bqkv, *bo, *b1, *b2;
+    // folded LayerNorm (gemm.hip EPI_LN_*), derived from the loaded tensors before the first forward: column sums sum_k gamma_k W[n,k]
+    // and biases b + W beta of the two GEMMs that consume a LayerNorm (qkv after layer_norm1, fc1 after layer_norm2)
+    float *s_qkv, *b2_qkv, *s_fc1, *b2_fc1;
 };
 
 struct pgv_vit {
@@ -32,6 +38,7 @@ struct pgv_vit {
     std::vector<VitLayer> layers;
     std::set<std::string> loaded;
     int expected = 0;
+    bool folded = false;           // the derived vectors above are current (reset by every tensor load)
     int max_chunk_frames = 1024;   // frames per pass (workspace 5.8 GB at 224 px): one pass for the 800-frame bench batch -> 3.75 % fewer GEMM tile rounds than 2 x 400
 };
 
@@ -51,12 +58,13 @@ extern "C" int pgv_vit_create(pgv_ctx* ctx, const pgv_vit_config* cfg, int dtype
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += pgv_align(bytes); return o; };
     const size_t o_patch = take(C * v->Kp * 2), o_cls = take(C * 4), o_pos = take((size_t)v->tokens * C * 4), o_pg = take(C * 4), o_pb = take(C * 4);
-    struct LO { size_t ln1g, ln1b, ln2g, ln2b, wqkv, wo, w1, w2, bqkv, bo, b1, b2; };
+    struct LO { size_t ln1g, ln1b, ln2g, ln2b, wqkv, wo, w1, w2, bqkv, bo, b1, b2, sqkv, b2qkv, sfc1, b2fc1; };
     std::vector<LO> lo(L);
     for (size_t i = 0; i < L; ++i) {
         lo[i].ln1g = take(C * 4); lo[i].ln1b = take(C * 4); lo[i].ln2g = take(C * 4); lo[i].ln2b = take(C * 4);
         lo[i].wqkv = take(3 * C * C * 2); lo[i].wo = take(C * C * 2); lo[i].w1 = take(I * C * 2); lo[i].w2 = take(C * I * 2);
         lo[i].bqkv = take(3 * C * 4); lo[i].bo = take(C * 4); lo[i].b1 = take(I * 4); lo[i].b2 = take(C * 4);
+        lo[i].sqkv = take(3 * C * 4); lo[i].b2qkv = take(3 * C * 4); lo[i].sfc1 = take(I * 4); lo[i].b2fc1 = take(I * 4);
     }
     hipError_t e = hipMalloc((void**)&v->blob, off);
     if (e != hipSuccess) { delete v; pgv_set_error("pgv_vit_create: hipMalloc(%zu MiB): %s", off >> 20, hipGetErrorString(e)); return PGV_ENOMEM; }
@@ -69,6 +77,7 @@ extern "C" int pgv_vit_create(pgv_ctx* ctx, const pgv_vit_config* cfg, int dtype
         l.ln1_g = (float*)(b + lo[i].ln1g); l.ln1_b = (float*)(b + lo[i].ln1b); l.ln2_g = (float*)(b + lo[i].ln2g); l.ln2_b = (float*)(b + lo[i].ln2b);
         l.wqkv = b + lo[i].wqkv; l.wo = b + lo[i].wo; l.w1 = b + lo[i].w1; l.w2 = b + lo[i].w2;
         l.bqkv = (float*)(b + lo[i].bqkv); l.bo = (float*)(b + lo[i].bo); l.b1 = (float*)(b + lo[i].b1); l.b2 = (float*)(b + lo[i].b2);
+        l.s_qkv = (float*)(b + lo[i].sqkv); l.b2_qkv = (float*)(b + lo[i].b2qkv); l.s_fc1 = (float*)(b + lo[i].sfc1); l.b2_fc1 = (float*)(b + lo[i].b2fc1);
     }
     v->expected = 5 + 16 * (int)L;   // post_layernorm is accepted but not needed for hidden_states
     *out = v;
@@ -129,7 +138,14 @@ extern "C" int pgv_vit_load_tensor(pgv_vit* v, const char* name_in, const void* 
               (long long)numel, d.rows, d.cols);
     PGV_TRY(pgv_pack_tensor(d, data, src_dtype, on_device, (hipStream_t)stream));
     if (counted) v->loaded.insert(name);
+    v->folded = false;
     return PGV_OK;
+}
+
+static bool ln_fold_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("PGV_VIT_LN_FOLD"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v == 1;
 }
 
 extern "C" int pgv_vit_forward(pgv_ctx* ctx, pgv_vit* v, const void* d_pixels, int T, int n_layers, void* d_hidden, void* stream) {
@@ -139,17 +155,29 @@ extern "C" int pgv_vit_forward(pgv_ctx* ctx, pgv_vit* v, const void* d_pixels, i
     if (pgv_vit_missing(v) != 0) { pgv_set_error("pgv_vit_forward: %d weight tensors not loaded", pgv_vit_missing(v)); return PGV_ESTATE; }
     hipStream_t s = (hipStream_t)stream;
     const int C = v->cfg.hidden, I = v->cfg.inter, N = v->tokens, P = v->patches, S = v->cfg.image;
+    const bool fold = ln_fold_enabled();
+    if (fold && !v->folded) {          // derived vectors of the folded LayerNorm, once per (re)load
+        for (auto& l : v->layers) {
+            PGV_TRY(pgv_launch_ln_fold(v->dtype, l.wqkv, l.bqkv, l.ln1_g, l.ln1_b, l.s_qkv, l.b2_qkv, 3 * C, C, s));
+            PGV_TRY(pgv_launch_ln_fold(v->dtype, l.w1, l.b1, l.ln2_g, l.ln2_b, l.s_fc1, l.b2_fc1, I, C, s));
+        }
+        v->folded = true;
+    }
     const int Tc_max = T < v->max_chunk_frames ? T : v->max_chunk_frames;
     const size_t Mmax = (size_t)Tc_max * N;
+    const int NP = C / 64;             // 64-column pieces of a residual row (partial statistics of the folded LayerNorm)
     const size_t b_resid = pgv_align(Mmax * C * 4), b_xn = pgv_align(Mmax * C * 2), b_qkv = pgv_align(Mmax * 3 * C * 2), b_ao = pgv_align(Mmax * C * 2),
-                 b_h = pgv_align(Mmax * I * 2 > (size_t)Tc_max * P * ((size_t)v->Kp * 2 + C * 4) + 512 ? Mmax * I * 2 : (size_t)Tc_max * P * ((size_t)v->Kp * 2 + C * 4) + 512);
-    PGV_TRY(pgv_ws_reserve(ctx, b_resid + b_xn + b_qkv + b_ao + b_h, s));
+                 b_h = pgv_align(Mmax * I * 2 > (size_t)Tc_max * P * ((size_t)v->Kp * 2 + C * 4) + 512 ? Mmax * I * 2 : (size_t)Tc_max * P * ((size_t)v->Kp * 2 + C * 4) + 512),
+                 b_part = pgv_align(Mmax * NP * 8), b_stat = pgv_align(Mmax * 8);
+    PGV_TRY(pgv_ws_reserve(ctx, b_resid + b_xn + b_qkv + b_ao + b_h + b_part + b_stat, s));
     float* resid = (float*)pgv_ws_alloc(ctx, b_resid);
     char* xn = (char*)pgv_ws_alloc(ctx, b_xn);
     char* qkv = (char*)pgv_ws_alloc(ctx, b_qkv);
     char* ao = (char*)pgv_ws_alloc(ctx, b_ao);
     char* hbuf = (char*)pgv_ws_alloc(ctx, b_h);
-    PGV_CHECK(resid && xn && qkv && ao && hbuf, "pgv_vit_forward: workspace exhausted");
+    float* part = (float*)pgv_ws_alloc(ctx, b_part);
+    float* rowstat = (float*)pgv_ws_alloc(ctx, b_stat);
+    PGV_CHECK(resid && xn && qkv && ao && hbuf && part && rowstat, "pgv_vit_forward: workspace exhausted");
 
     for (int t0 = 0; t0 < T; t0 += Tc_max) {
         const int Tc = (T - t0) < Tc_max ? (T - t0) : Tc_max;
@@ -162,9 +190,34 @@ extern "C" int pgv_vit_forward(pgv_ctx* ctx, pgv_vit* v, const void* d_pixels, i
         GemmArgs g{};
         g.A = a0; g.lda = v->Kp; g.W = v->patch_w; g.ldw = v->Kp; g.bias = nullptr; g.C = pe; g.ldc = C; g.M = Tc * P; g.N = C; g.K = v->Kp; g.epi = PGV_EPI_F32;
         PGV_TRY(pgv_launch_gemm(ctx, v->dtype, g, s));
-        PGV_TRY(pgv_launch_embed_ln(pe, v->cls, v->pos, v->pre_g, v->pre_b, v->cfg.eps, resid, M, N, C, s));
+        const bool f0 = fold && n_layers > 0;
+        PGV_TRY(pgv_launch_embed_ln(v->dtype, pe, v->cls, v->pos, v->pre_g, v->pre_b, v->cfg.eps, resid, M, N, C, f0 ? v->layers[0].ln1_g : nullptr, xn, rowstat, s));
         for (int li = 0; li < n_layers; ++li) {
             const VitLayer& l = v->layers[li];
+            if (fold) {
+                // LayerNorm has no launch of its own (gemm.hip, EPI_LN_*): xn = round16(resid * ln1_g), rowstat = (mean, rstd) of resid
+                g = GemmArgs{}; g.A = xn; g.lda = C; g.W = l.wqkv; g.ldw = C; g.bias = l.b2_qkv; g.C = qkv; g.ldc = 3 * C; g.M = M; g.N = 3 * C; g.K = C;
+                g.epi = PGV_EPI_LN_BIAS; g.rowstat = rowstat; g.colsum = l.s_qkv;
+                PGV_TRY(pgv_launch_gemm(ctx, v->dtype, g, s));
+                PGV_TRY(pgv_launch_vit_attn(ctx, v->dtype, qkv, 3 * C, ao, C, Tc, N, C, v->cfg.heads, s));
+                g = GemmArgs{}; g.A = ao; g.lda = C; g.W = l.wo; g.ldw = C; g.bias = l.bo; g.C = resid; g.ldc = C; g.M = M; g.N = C; g.K = C;
+                g.epi = PGV_EPI_BIAS_RESID_LNOUT; g.gnext = l.ln2_g; g.x16 = xn; g.ldx16 = C; g.stats_part = part;
+                PGV_TRY(pgv_launch_gemm(ctx, v->dtype, g, s));
+                PGV_TRY(pgv_launch_ln_stats(part, rowstat, M, NP, C, v->cfg.eps, s));
+                g = GemmArgs{}; g.A = xn; g.lda = C; g.W = l.w1; g.ldw = C; g.bias = l.b2_fc1; g.C = hbuf; g.ldc = I; g.M = M; g.N = I; g.K = C;
+                g.epi = PGV_EPI_LN_BIAS_QGELU; g.rowstat = rowstat; g.colsum = l.s_fc1;
+                PGV_TRY(pgv_launch_gemm(ctx, v->dtype, g, s));
+                g = GemmArgs{}; g.A = hbuf; g.lda = I; g.W = l.w2; g.ldw = I; g.bias = l.b2; g.C = resid; g.ldc = C; g.M = M; g.N = C; g.K = I;
+                if (li + 1 < n_layers) {
+                    g.epi = PGV_EPI_BIAS_RESID_LNOUT; g.gnext = v->layers[li + 1].ln1_g; g.x16 = xn; g.ldx16 = C; g.stats_part = part;
+                    PGV_TRY(pgv_launch_gemm(ctx, v->dtype, g, s));
+                    PGV_TRY(pgv_launch_ln_stats(part, rowstat, M, NP, C, v->cfg.eps, s));
+                } else {
+                    g.epi = PGV_EPI_BIAS_RESID;          // the last executed layer feeds no LayerNorm
+                    PGV_TRY(pgv_launch_gemm(ctx, v->dtype, g, s));
+                }
+                continue;
+            }
             PGV_TRY(pgv_launch_layernorm(v->dtype, resid, l.ln1_g, l.ln1_b, v->cfg.eps, xn, M, C, s));
             g = GemmArgs{}; g.A = xn; g.lda = C; g.W = l.wqkv; g.ldw = C; g.bias = l.bqkv; g.C = qkv; g.ldc = 3 * C; g.M = M; g.N = 3 * C; g.K = C; g.epi = PGV_EPI_BIAS;
             PGV_TRY(pgv_launch_gemm(ctx, v->dtype, g, s));
