@@ -45,12 +45,15 @@ struct KArgs {
 // after the normalisation to before it (same relative size).  Saves the read of the fp32 residual + the launch of every LayerNorm.
 enum { EPI_LN_BIAS = 8, EPI_LN_BIAS_QGELU = 9, EPI_BIAS_RESID_LNOUT = 10 };
 
-// sum over each aligned group of 16 lanes (DPP: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_ror:4, row_ror:8)
+// Sum over each aligned group of 16 lanes, every lane receiving a BIT-IDENTICAL total: a butterfly of exchanges (quad_perm [1,0,3,2],
+// quad_perm [2,3,0,1], row_half_mirror, row_mirror) adds the same two partial sums on both sides of every exchange, and a + b == b + a.
+// (A rotate-based reduction -- row_ror:4, row_ror:8 -- associates differently in different quads: (q0+q1)+(q2+q3) vs (q1+q2)+(q3+q0);
+// with the lane that reports a row depending on the row's position, LayerNorm statistics became position dependent in the last bit.)
 __device__ __forceinline__ float row16_sum(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
     return v;
 }
 
