@@ -29,7 +29,7 @@ DEV = "cuda:0"
 
 TOL_7B_FP16 = 8.1e-3      # normwise logits error: 1.2 x the 6.72e-3 measured on MI355X (2 layers: 1.84e-3; sixteen-fold depth -> x sqrt(16) = 4:
                           # independent 16-bit roundings of xn / qkv / P / attention out / SwiGLU act per layer; the residual stream itself is fp32)
-TOL_13B_FP8_FP16 = 1.2e-2   # placeholder until measured (expected ~7.5e-3 x 1.2)
+TOL_13B_FP8_FP16 = 1.33e-2  # 1.2 x the worst decode-step error measured on MI355X (1.105e-2; prefill 6.98e-3)
 
 
 def rel(a, b) -> float:

@@ -317,9 +317,12 @@ __device__ __forceinline__ typename T::v8 fp8x8_to_v8(unsigned lo, unsigned hi) 
 // NW = waves per workgroup (the K split inside a workgroup).  8 everywhere except the residual producers, which cannot split K across
 // workgroups any more (the workgroup that owns 16 output rows must see their complete sums to emit xg and the sum of squares) and use 16
 // waves instead, so that a CU still has 16 waves' worth of weight loads in flight with one workgroup per CU.
-template <typename T, int MODE, bool W8, int NW>
+// TL = row blocks of 16 per workgroup.  Every row block of a workgroup multiplies the SAME x fragments, so the activation loads -- which are
+// re-read by every workgroup and cost as many requests on the CU's load path as the weights of ONE row block -- are shared: 2 for gate/up
+// (the SiLU pair), 3 for qkv when the row-block count divides (7B: 768 = 3 x 256 workgroups, one per CU), 1 otherwise.
+template <typename T, int MODE, bool W8, int NW, int TL = (MODE == GV_SWIGLU ? 2 : 1)>
 __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
-    constexpr int TILES = (MODE == GV_SWIGLU) ? 2 : 1;
+    constexpr int TILES = TL;
     __shared__ f32x4_t red[NW][TILES][64];
     __shared__ f32x4_t ssq_red[NW][4];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -333,7 +336,8 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
         rb[0] = base >> 4;                                       // gate row block
         rb[1] = (base + 32) >> 4;                                // matching up row block
     } else {
-        rb[0] = blockIdx.x;
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) rb[t] = blockIdx.x * TILES + t;
     }
     // folded RMSNorm, consumer side: this thread's share of the sum-of-squares partials (L2 hits), requested before the weight stream
     // (three independent loads whose first USE is after the weight loop: summing them here would park the wave on an L2 round trip
@@ -371,7 +375,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
         const char* wp[TILES];
 #pragma unroll
         for (int t = 0; t < TILES; ++t) wp[t] = p.W + ((size_t)rb[t] * k64) * 1024 + lane * 16;
-        constexpr int U = (TILES == 2) ? 4 : 8;
+        constexpr int U = (TILES >= 2) ? 4 : 8;
         const int j_end = min(k64, (int)(blockIdx.y + 1) * (p.kb_per >> 1));
         int j = blockIdx.y * (p.kb_per >> 1) + w;
         for (; j + NW * (U - 1) < j_end; j += NW * U) {
@@ -426,7 +430,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
         const char* wp[TILES];
 #pragma unroll
         for (int t = 0; t < TILES; ++t) wp[t] = p.W + ((size_t)rb[t] * kblocks) * 1024 + lane * 16;
-        constexpr int U = (TILES == 2) ? 2 : 4;
+        constexpr int U = (TILES >= 2) ? 2 : 4;
         const int kb_end = min(kblocks, (int)(blockIdx.y + 1) * p.kb_per);       // 32-blocks; kb_per is even
         const int j_end = (kb_end + 1) >> 1;                                     // 64-groups (the last may hold one 32-block)
         int j = ((blockIdx.y * p.kb_per) >> 1) + w;
@@ -511,7 +515,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
 #pragma unroll
         for (int t = 0; t < TILES; ++t) tot[t] *= rstd;
     }
-    const int n0 = blockIdx.x * 16 + kg * 4;
+    const int n0 = (MODE == GV_SWIGLU ? (int)blockIdx.x : rb[0]) * 16 + kg * 4;
     if constexpr (MODE == GV_RESIDNORM) {
         // r = resid + y (fp32, written back); xg = round16(r * gamma); sum of r^2 over this workgroup's 16 rows per batch column
         float sq = 0.f;
@@ -548,7 +552,9 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
         for (int r = 0; r < 4; ++r) { const float g = tot[0][r]; v[r] = g * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(g * -1.4426950408889634f)) * tot[1][r]; }   // same SiLU as gemm.hip
         *(u32x2_t*)(p.out + ((size_t)b * p.ldo + n0) * 2) = pack4<T>(v[0], v[1], v[2], v[3]);
     } else if constexpr (MODE == GV_STORE16) {
-        *(u32x2_t*)(p.out + ((size_t)b * p.ldo + n0) * 2) = pack4<T>(tot[0][0], tot[0][1], tot[0][2], tot[0][3]);
+#pragma unroll
+        for (int t = 0; t < TILES; ++t)
+            *(u32x2_t*)(p.out + ((size_t)b * p.ldo + n0 + t * 16) * 2) = pack4<T>(tot[t][0], tot[t][1], tot[t][2], tot[t][3]);
     } else if constexpr (MODE == GV_RESID) {
         f32x4_t* rp = (f32x4_t*)(p.out + ((size_t)b * p.ldo + n0) * 4);
         *rp = *rp + tot[0];
@@ -1055,8 +1061,15 @@ int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void
     pgv_prof_begin(ctx, 3, s);
 #define PGV_GEMV(MODE_, W8_, NW_) PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gemv_mfma_kernel<T, MODE_, W8_, NW_>), dim3(grid, splits), dim3(NW_ * 64), 0, s, a))
 #define PGV_GEMV2(MODE_, NW_) do { if (w8) PGV_GEMV(MODE_, true, NW_); else PGV_GEMV(MODE_, false, NW_); } while (0)
+#define PGV_GEMV_TL3(W8_) PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gemv_mfma_kernel<T, GV_STORE16, W8_, 8, 3>), dim3(grid / 3, 1), dim3(512), 0, s, a))
+    static int tl3 = -1;
+    if (tl3 < 0) { const char* e = getenv("PGV_GEMV_TL3"); tl3 = (e && e[0] == '0') ? 0 : 1; }
     switch (mode) {
-        case GV_STORE16: PGV_GEMV2(GV_STORE16, 8); break;
+        case GV_STORE16:
+            // three row blocks per workgroup when that puts at most ~one workgroup on every CU and nothing is left over (7B qkv: 768 -> 256)
+            if (tl3 && grid % 3 == 0 && grid / 3 <= ctx->num_cu && grid / 3 >= ctx->num_cu / 2) { if (w8) PGV_GEMV_TL3(true); else PGV_GEMV_TL3(false); }
+            else PGV_GEMV2(GV_STORE16, 8);
+            break;
         case GV_RESID: PGV_GEMV2(GV_RESID, 8); break;
         case GV_SWIGLU: PGV_GEMV2(GV_SWIGLU, 8); break;
         case GV_F32: PGV_GEMV2(GV_F32, 8); break;
@@ -1064,6 +1077,7 @@ int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void
         case GV_RESIDNORM: PGV_GEMV2(GV_RESIDNORM, 16); break;
         default: pgv_set_error("gemv: bad mode %d", mode); return PGV_EINVAL;
     }
+#undef PGV_GEMV_TL3
 #undef PGV_GEMV2
 #undef PGV_GEMV
     pgv_prof_end(ctx, 3, s, 2.0 * B * (double)N * K, (w8 ? 1.0 : 2.0) * (double)N * K);
