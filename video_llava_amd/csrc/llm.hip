@@ -10,7 +10,6 @@
 
 int pgv_launch_rmsnorm(int dtype, const float* x, const float* g, float eps, void* y, int rows, int cols, hipStream_t s);
 int pgv_launch_embed_splice(int dtype, const int* row_src, const void* embed, const void* video, float* resid, int M, int H, hipStream_t s);
-int pgv_launch_embed_tok(int dtype, const int* tok, const void* embed, float* resid, int B, int H, hipStream_t s);
 int pgv_launch_gather_rows(const float* src, const int* rows, float* dst, int B, int H, hipStream_t s);
 int pgv_launch_rope_kv_write(int dtype, void* qkv, const int* row_b, const int* row_pos, const void* rope, void* Kc, void* Vc, int M, int H,
                              int heads, int max_seq, hipStream_t s);
@@ -25,8 +24,6 @@ int pgv_launch_unpack_blocked(int dtype, const void* src, float* dst, long long 
 int pgv_launch_final_prep(int dtype, const float* resid, const float* gamma, void* xg, float* ssq, int B, int H, hipStream_t s);
 int pgv_launch_decode_attn(pgv_ctx* ctx, int dtype, const void* qkv, const int* pos, const void* rope, void* Kc, void* Vc, void* out, int B, int H,
                            int heads, int max_seq, double bytes, hipStream_t s);
-int pgv_launch_argmax(const float* logits, int V, int B, int* next, int* pos, int* step, int* hist, int hist_stride, int* done, int eos, int flags,
-                      hipStream_t s);
 int pgv_launch_sample(const float* logits, int V, int B, float temperature, int top_k, const float* u, int u_stride, int u_by_step, int* next, int* pos,
                       int* step, int* hist, int hist_stride, int* done, int eos, int advance, hipStream_t s);
 int pgv_launch_argmax_parts(const float* val, const int* idx, int nblk, int V, int B, int* next, int* pos, int* step, int* hist, int hist_stride, int* done,

@@ -43,22 +43,6 @@ __global__ __launch_bounds__(256) void embed_splice_kernel(const int* __restrict
     }
 }
 
-// decode: resid[b] = embed[tok[b]]
-template <typename T>
-__global__ __launch_bounds__(256) void embed_tok_kernel(const int* __restrict__ tok, const typename T::elem* __restrict__ embed,
-                                                        float* __restrict__ resid, int H) {
-    const int b = blockIdx.x;
-    const typename T::elem* p = embed + (size_t)tok[b] * H;
-    for (int c = threadIdx.x * 8; c < H; c += 256 * 8) {
-        const typename T::v8 v = *(const typename T::v8*)(p + c);
-        f32x4_t a, bb;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { a[e] = (float)v[e]; bb[e] = (float)v[4 + e]; }
-        *(f32x4_t*)(resid + (size_t)b * H + c) = a;
-        *(f32x4_t*)(resid + (size_t)b * H + c + 4) = bb;
-    }
-}
-
 // gather rows (last token of every sequence) of the fp32 residual
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ rows, float* __restrict__ dst, int H) {
     const int b = blockIdx.x;
@@ -643,6 +627,22 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const typename T::
     typename T::elem* vcache = Vc + ((size_t)b * heads + h) * max_seq * HD;
     const int slot = lane >> 4, dc = lane & 15;
 
+    // The first DEPTH rounds of K / V loads go out before anything else (they need only `pos`): the query's RoPE below -- two L2 round
+    // trips for the rope table and q -- runs while they are in flight instead of in front of them.  The cache is streamed once per token
+    // (2.4 GB per token step at 8 sequences: no reuse in L2 / Infinity Cache), hence non-temporal loads like the GEMVs' weights.
+    const int n_keys = pos;                            // cached keys; the fresh key (index pos) is handled from registers below
+    const int key0 = w * 4 + slot;
+    // DEPTH rounds of KPR keys are kept in flight per workgroup (DEPTH x 4 x 16-B loads per lane)
+    constexpr int DEPTH = NW == 8 ? 4 : 2;
+    typename T::v8 kq[DEPTH][2], vq[DEPTH][2];
+    auto load = [&](int key, typename T::v8& kk_, typename T::v8& vv_) {
+        const int kc = max(0, min(key, n_keys - 1));   // clamped rows are masked below
+        kk_ = __builtin_nontemporal_load((const typename T::v8*)(kcache + (size_t)kc * HD + dc * 8));
+        vv_ = __builtin_nontemporal_load((const typename T::v8*)(vcache + (size_t)kc * HD + dc * 8));
+    };
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) { load(key0 + KPR * d, kq[d][0], vq[d][0]); load(key0 + KPR * d + KPR / 2, kq[d][1], vq[d][1]); }
+
     // rotate-half RoPE on this lane's 8 dims d = dc*8 + e of a 128-wide row x: d < 64: x[d] c[d] - x[d+64] s[d];  d >= 64: x[d] c[d-64] + x[d-64] s[d-64]
     // (values rounded to the activation dtype like the prefill path writes them)
     const int j0 = (dc & 7) * 8;                       // rope index of e = 0
@@ -664,16 +664,6 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const typename T::
     for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[u][e] = 0.f;
-    const int n_keys = pos;                            // cached keys; the fresh key (index pos) is handled from registers below
-    const int key0 = w * 4 + slot;
-    // DEPTH rounds of KPR keys are kept in flight per workgroup (DEPTH x 4 x 16-B loads per lane)
-    constexpr int DEPTH = NW == 8 ? 4 : 2;
-    typename T::v8 kq[DEPTH][2], vq[DEPTH][2];
-    auto load = [&](int key, typename T::v8& kk_, typename T::v8& vv_) {
-        const int kc = max(0, min(key, n_keys - 1));   // clamped rows are masked below
-        kk_ = *(const typename T::v8*)(kcache + (size_t)kc * HD + dc * 8);
-        vv_ = *(const typename T::v8*)(vcache + (size_t)kc * HD + dc * 8);
-    };
     auto update = [&](int u, const typename T::v8& kf, const typename T::v8& vf, bool valid) {
         float s = 0.f;
 #pragma unroll
@@ -681,15 +671,13 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const typename T::
         s = row16_sum(s);
         if (valid) {
             const float mn = fmaxf(m[u], s);
-            const float alpha = exp2f(m[u] - mn), pv = exp2f(s - mn);
+            const float alpha = __builtin_amdgcn_exp2f(m[u] - mn), pv = __builtin_amdgcn_exp2f(s - mn);     // arguments <= 0: the raw v_exp_f32 is exact enough and flushes to 0
             m[u] = mn;
             l[u] = l[u] * alpha + pv;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[u][e] = o[u][e] * alpha + pv * (float)vf[e];
         }
     };
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) { load(key0 + KPR * d, kq[d][0], vq[d][0]); load(key0 + KPR * d + KPR / 2, kq[d][1], vq[d][1]); }
 
     // fresh token (overlaps the first loads): wave 0 appends the rotated k and v to the cache; its slot-0 lanes also keep them for the softmax
     typename T::v8 knew, vnew;
@@ -756,47 +744,10 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const typename T::
 }
 
 // ---------------------------------------------------------------------------------------------
-// greedy argmax over fp32 logits (first index wins ties, like torch.argmax on CPU) + bookkeeping.
-// advance != 0: also pos[b]++, hist[b][step[b]++] = token, EOS stickiness.
+// greedy pick (first index wins ties, like torch.argmax on CPU) + bookkeeping: advance != 0 also does pos[b]++,
+// hist[b][step[b]++] = token, EOS stickiness.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void argmax_kernel(const float* __restrict__ logits, int V, int* __restrict__ next, int* __restrict__ pos,
-                                                      int* __restrict__ step, int* __restrict__ hist, int hist_stride, int* __restrict__ done,
-                                                      int eos, int advance) {
-    __shared__ float sv[16];
-    __shared__ int si[16];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const float* lg = logits + (size_t)b * V;
-    float best = -INFINITY;
-    int bi = 0x7fffffff;
-    for (int i = tid; i < V; i += 1024) {
-        const float v = lg[i];
-        if (v > best) { best = v; bi = i; }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const float ov = __shfl_xor(best, off, 64);
-        const int oi = __shfl_xor(bi, off, 64);
-        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-    }
-    if ((tid & 63) == 0) { sv[tid >> 6] = best; si[tid >> 6] = bi; }
-    __syncthreads();
-    if (tid == 0) {
-        for (int i = 1; i < 16; ++i)
-            if (sv[i] > best || (sv[i] == best && si[i] < bi)) { best = sv[i]; bi = si[i]; }
-        int tok = bi < V ? bi : 0;               // all-NaN logits leave bi at its sentinel: never hand an out-of-range id to the embedding gather
-        if (advance) {
-            if (done[b]) tok = eos;
-            else if (eos >= 0 && tok == eos) done[b] = 1;
-            hist[(size_t)b * hist_stride + step[b]] = tok;
-            step[b] += 1;
-            pos[b] += 1;
-        }
-        next[b] = tok;
-    }
-}
-
-
-// greedy pick from the lm_head GEMV's per-workgroup candidates (GemvArgs::amax_*): same result as argmax_kernel on the full logits
+// greedy pick from the lm_head GEMV's per-workgroup candidates (GemvArgs::amax_*): same result as a scan of the full logits
 // (largest value, smallest index on ties, NaN never), 16x fewer values to scan.
 __global__ __launch_bounds__(256) void argmax_parts_kernel(const float* __restrict__ val, const int* __restrict__ idx, int nblk, int V, int* __restrict__ next,
                                                            int* __restrict__ pos, int* __restrict__ step, int* __restrict__ hist, int hist_stride,
@@ -997,10 +948,6 @@ int pgv_launch_embed_splice(int dtype, const int* row_src, const void* embed, co
                                                     (const typename T::elem*)video, resid, H));
     return PGV_OK;
 }
-int pgv_launch_embed_tok(int dtype, const int* tok, const void* embed, float* resid, int B, int H, hipStream_t s) {
-    PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((embed_tok_kernel<T>), dim3(B), dim3(256), 0, s, tok, (const typename T::elem*)embed, resid, H));
-    return PGV_OK;
-}
 int pgv_launch_gather_rows(const float* src, const int* rows, float* dst, int B, int H, hipStream_t s) {
     hipLaunchKernelGGL(gather_rows_kernel, dim3(B), dim3(256), 0, s, src, rows, dst, H);
     return PGV_OK;
@@ -1099,12 +1046,6 @@ int pgv_launch_decode_attn(pgv_ctx* ctx, int dtype, const void* qkv, const int* 
                                                         (const float2*)rope, (typename T::elem*)Kc, (typename T::elem*)Vc, (typename T::elem*)out, H, heads,
                                                         max_seq, sc));
     pgv_prof_end(ctx, 4, s, 0.0, bytes);
-    return PGV_OK;
-}
-
-int pgv_launch_argmax(const float* logits, int V, int B, int* next, int* pos, int* step, int* hist, int hist_stride, int* done, int eos, int advance,
-                      hipStream_t s) {
-    hipLaunchKernelGGL(argmax_kernel, dim3(B), dim3(1024), 0, s, logits, V, next, pos, step, hist, hist_stride, done, eos, advance);
     return PGV_OK;
 }
 
