@@ -380,3 +380,27 @@ def test_nearest_resize_index_rule():
         iy = np.minimum(np.floor(np.arange(s, dtype=np.float32) * sh).astype(np.int64), h - 1)
         ix = np.minimum(np.floor(np.arange(s, dtype=np.float32) * sw).astype(np.int64), w - 1)
         assert np.array_equal(got, a[:, iy][:, :, ix]), (h, w, s)
+
+
+def test_frame_directory_front_end(tmp_path):
+    """load_video without decord: a directory of image files (one frame per file) is sampled with get_seq_frames exactly like a decoded
+    video (reference eval/model_utils.py:27-36) and resized with the reference's nearest rule."""
+    from PIL import Image
+    from video_llava_amd import feature_extraction as fx
+    from video_llava_amd.eval.model_utils import get_seq_frames
+    rng = np.random.default_rng(3)
+    clip = rng.integers(0, 256, (130, 24, 40, 3), dtype=np.uint8)
+    d = tmp_path / "clip_frames"
+    d.mkdir()
+    for i, f in enumerate(clip):
+        Image.fromarray(f).save(d / f"{i:06d}.png")                      # lossless
+    (d / "notes.txt").write_text("ignored")
+    native = fx.sample_frames(str(d))
+    assert native.shape == (100, 24, 40, 3) and np.array_equal(native, clip[get_seq_frames(130, 100)])
+    got = fx.load_video(str(d), shape=(14, 14))
+    assert got.shape == (100, 14, 14, 3) and np.array_equal(got, fx.resize_nearest(native, (14, 14)))
+    nf = fx.load_video(str(d), shape=(14, 14), device_resize=True)
+    assert isinstance(nf, fx.NativeFrames) and nf.shape == (14, 14) and np.array_equal(nf.resized(), got)
+    with pytest.raises(ValueError, match="no image files"):
+        (tmp_path / "empty").mkdir()
+        fx.sample_frames(str(tmp_path / "empty"))

@@ -138,6 +138,9 @@ def answer_tasks(args, tasks, components, load_frames, rank, world):
     return preds
 
 
+DECORD_FREE_FORMATS = (".npy", "")      # a uint8 [T,H,W,3] array, or a directory of frame images named like the video (no extension)
+
+
 def first_existing(video_dir, stem, formats):
     """First existing `{stem}{ext}` in the given extension order; None when absent."""
     import os

@@ -39,7 +39,7 @@ def run_inference(args, components=None, load_frames=None, questions=("Q",), pre
     os.makedirs(args.output_dir, exist_ok=True)
     tasks = []
     for sample in gt_contents:                                       # :57-69 -- extension order of the reference
-        path = _sharded.first_existing(args.video_dir, sample["video_name"], VIDEO_FORMATS + [".npy"])
+        path = _sharded.first_existing(args.video_dir, sample["video_name"], VIDEO_FORMATS + list(_sharded.DECORD_FREE_FORMATS))
         tasks += [{"path": path, "name": sample["video_name"], "question": sample[q]} for q in questions]
     preds = _sharded.answer_tasks(args, tasks, components, load_frames, rank, world)
     output_list = []

@@ -31,7 +31,7 @@ def parse_args(argv=None):
     return add_runtime_arguments(parser).parse_args(argv)
 
 
-def find_video(video_dir, video_name, extra_formats=(".npy",)):
+def find_video(video_dir, video_name, extra_formats=(".npy", "")):
     """First existing `v_{video_name}{ext}` in the reference's extension order (:70-76); None when absent."""
     for fmt in list(VIDEO_FORMATS) + list(extra_formats):
         path = os.path.join(video_dir, f"v_{video_name}{fmt}")

@@ -39,7 +39,7 @@ def run_inference(args, components=None, load_frames=None, video_stem=None, exte
     tasks = []
     for sample in gt_contents:
         stem = video_stem(sample)
-        tasks.append({"path": _sharded.first_existing(args.video_dir, stem, list(extensions) + [".npy"]), "name": stem, "question": sample["question"]})
+        tasks.append({"path": _sharded.first_existing(args.video_dir, stem, list(extensions) + list(_sharded.DECORD_FREE_FORMATS)), "name": stem, "question": sample["question"]})
     preds = _sharded.answer_tasks(args, tasks, components, load_frames, rank, world)
     output_list = []
     for sample, p in zip(gt_contents, preds):

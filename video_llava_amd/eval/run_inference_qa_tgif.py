@@ -37,7 +37,7 @@ def run_inference(args, components=None, load_frames=None):
     load_frames = load_frames or load_video_from_gif
     os.makedirs(args.output_dir, exist_ok=True)
     rows = [row.to_dict() for _, row in pd.read_csv(args.gt_file, sep="\t").iterrows()]
-    tasks = [{"path": _sharded.first_existing(args.video_dir, r["gif_name"], [".gif", ".npy"]), "name": r["gif_name"], "question": r["question"]} for r in rows]
+    tasks = [{"path": _sharded.first_existing(args.video_dir, r["gif_name"], [".gif", *_sharded.DECORD_FREE_FORMATS]), "name": r["gif_name"], "question": r["question"]} for r in rows]
     preds = _sharded.answer_tasks(args, tasks, components, load_frames, rank, world)
     output_list = []
     for r, p in zip(rows, preds):

@@ -54,8 +54,24 @@ def resize_nearest(arr: np.ndarray, shape) -> np.ndarray:
     return t.permute(0, 2, 3, 1).to(torch.uint8).numpy()
 
 
+IMAGE_EXTENSIONS = (".jpg", ".jpeg", ".png", ".bmp", ".webp")
+
+
 def sample_frames(vis_path, num_frm=100) -> np.ndarray:
-    """Up to `num_frm` uniformly sampled frames (get_seq_frames) at the file's own resolution, uint8 [k, H, W, 3]."""
+    """Up to `num_frm` uniformly sampled frames (get_seq_frames) at the source's own resolution, uint8 [k, H, W, 3].
+    Sources: a video file (through `decord`, like the reference), a `.npy` array of frames, or a DIRECTORY of image files (one frame per
+    file, lexicographic order -- what `ffmpeg -i clip.mp4 frames/%06d.jpg` leaves behind): the two decord-free front ends."""
+    if os.path.isdir(vis_path):
+        from PIL import Image
+        names = sorted(n for n in os.listdir(vis_path) if n.lower().endswith(IMAGE_EXTENSIONS))
+        if not names:
+            raise ValueError(f"{vis_path}: no image files ({', '.join(IMAGE_EXTENSIONS)})")
+        total = len(names)
+        k = min(total, num_frm)
+        frames = [np.asarray(Image.open(os.path.join(vis_path, names[i])).convert("RGB")) for i in get_seq_frames(total, k)]
+        if any(f.shape != frames[0].shape for f in frames):
+            raise ValueError(f"{vis_path}: frames of different sizes")
+        return np.ascontiguousarray(np.stack(frames))
     if str(vis_path).endswith(VIDEO_EXTENSIONS_NPY):
         src = np.load(vis_path, mmap_mode="r")
         if src.dtype != np.uint8 or src.ndim != 4 or src.shape[-1] != 3:
