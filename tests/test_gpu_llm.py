@@ -272,6 +272,50 @@ def test_gemv_fp8_bit_equal_to_16bit_on_dequantised(ctx, dtype, mode, N, K, B):
     assert torch.equal(o16, o8)                                     # same weights, same accumulation order, exact scale
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("mode,N,K", [(0, 12288, 4096), (0, 1536, 1056), (2, 22016, 4096), (3, 515, 11040), (1, 512, 11008)])
+def test_gemv_batch_columns_are_independent(ctx, dtype, mode, N, K):
+    """A sequence's GEMV result must not depend on how many other sequences share the launch.  With B <= 8 the kernel fetches the x fragments
+    of two k-blocks in one wave-load (lanes of the unused batch columns carry the second block, a DPP move redistributes it); with B > 8 it
+    issues the two loads separately.  Rows 0..7 of a B = 8 and of a B = 11 launch on the same inputs must agree bit for bit -- 16-bit and fp8
+    weights, K with an odd number of 32-blocks (K = 1056, 11040: the last 64-column group is half empty) included."""
+    from video_llava_amd import _lib
+    g = torch.Generator().manual_seed(N + K)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dtype).to(DEV)
+    x = torch.randn(11, K, generator=g).to(dtype).to(DEV)
+    dc = _lib.dtype_code(dtype)
+    Np = (N + 15) // 16 * 16
+    wb = torch.zeros(Np, K, dtype=dtype, device=DEV)
+    _lib.check(ctx.lib.pgv_pack_blocked(ctx.handle, dc, w.data_ptr(), N, K, wb.data_ptr(), _lib.stream_ptr()))
+    fp8 = K % 64 == 0 and N % 16 == 0
+    if fp8:
+        w8 = torch.zeros(N * K, dtype=torch.uint8, device=DEV)
+        sc = torch.zeros(N, dtype=torch.float32, device=DEV)
+        _lib.check(ctx.lib.pgv_quantize_fp8_blocked(ctx.handle, dc, wb.data_ptr(), w8.data_ptr(), sc.data_ptr(), N, K, _lib.stream_ptr()))
+
+    def run(B, quantised):
+        if mode == 0:
+            out = torch.empty(B, N, dtype=dtype, device=DEV)
+        elif mode == 1:
+            out = torch.ones(B, N, dtype=torch.float32, device=DEV)
+        elif mode == 2:
+            out = torch.empty(B, N // 2, dtype=dtype, device=DEV)
+        else:
+            out = torch.empty(B, N, dtype=torch.float32, device=DEV)
+        if quantised:
+            _lib.check(ctx.lib.pgv_gemv_fp8(ctx.handle, dc, mode, w8.data_ptr(), sc.data_ptr(), x.data_ptr(), K, out.data_ptr(), out.shape[1], N, K, B,
+                                            _lib.stream_ptr()))
+        else:
+            _lib.check(ctx.lib.pgv_gemv(ctx.handle, dc, mode, wb.data_ptr(), x.data_ptr(), K, out.data_ptr(), out.shape[1], N, K, B, _lib.stream_ptr()))
+        return out
+    for quantised in ([False, True] if fp8 else [False]):
+        o8, o11, o1 = run(8, quantised), run(11, quantised), run(1, quantised)
+        assert torch.equal(o8, o11[:8]) and torch.equal(o1, o11[:1]), (mode, N, K, quantised)
+        ref = x[:8].cpu().float() @ w.cpu().float().t()                 # on the CPU: exact fp32 accumulation
+        if mode in (0, 3) and not quantised:
+            assert rel(o8, ref) < (8e-3 if dtype == torch.bfloat16 else 1e-3)
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 1e-3), (torch.bfloat16, 8e-3)])
 def test_llm_fp8_weights_vs_oracle(ctx, golden_dir, dtype, tol):
     cfg = synth.LlamaCfg(**{**synth.LLAMA_TINY.__dict__, "projector": "linear"})

@@ -16,7 +16,7 @@ int pgv_launch_rope_kv_write(int dtype, void* qkv, const int* row_b, const int* 
 int pgv_launch_prefill_attn(pgv_ctx* ctx, int dtype, const void* qkv, void* out, const void* Kc, const void* Vc, const int* cu, int B, int max_len,
                             int H, int heads, int max_seq, double flops, hipStream_t s);
 int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void* x, int ldx, void* out, int ldo, int N, int K, int B, hipStream_t s,
-                    int splits = 1, const float* wscale = nullptr, const GemvNorm* norm = nullptr);
+                    const float* wscale = nullptr, const GemvNorm* norm = nullptr);
 int pgv_launch_embed_tok_norm(int dtype, const int* tok, const void* embed, float* resid, const float* gamma, void* xg, float* ssq, int B, int H, hipStream_t s);
 int pgv_launch_quantize_fp8(int dtype, void* w16_blocked, void* w8_blocked, float* scales, long long N, long long K, hipStream_t s);
 int pgv_launch_unpack_blocked(int dtype, const void* src, float* dst, long long N, long long K, long long row_blk, long long blk_stride, long long row_off,
@@ -28,7 +28,7 @@ int pgv_launch_sample(const float* logits, int V, int B, float temperature, int 
                       int* step, int* hist, int hist_stride, int* done, int eos, int advance, hipStream_t s);
 int pgv_launch_argmax_parts(const float* val, const int* idx, int nblk, int V, int B, int* next, int* pos, int* step, int* hist, int hist_stride, int* done,
                             int eos, int advance, hipStream_t s);
-enum { GV_STORE16 = 0, GV_RESID = 1, GV_SWIGLU = 2, GV_F32 = 3, GV_PART = 4, GV_RESIDNORM = 5 };
+enum { GV_STORE16 = 0, GV_RESID = 1, GV_SWIGLU = 2, GV_F32 = 3, GV_RESIDNORM = 5 };
 enum { AM_INC_POS = 1, AM_RECORD = 2, AM_SAMPLE = 4 };
 
 constexpr int kMaxPos = 4096;   // max_position_embeddings of LLaVA-1.5 / Vicuna-1.5
@@ -334,7 +334,7 @@ static int lm_head_and_pick(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int B, int eos
     GemvNorm nm; nm.ssq_in = kv->ssq; nm.nparts_in = nparts; nm.hidden = H; nm.eps = m->cfg.eps;
     const bool greedy = !(flags & AM_SAMPLE);
     if (greedy) { nm.amax_val = kv->amax_val; nm.amax_idx = kv->amax_idx; }
-    PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_F32, m->fp8 ? m->q_head : m->lm_head, kv->xn, H, kv->logits, V, V, H, B, s, 1, m->fp8 ? m->s_head : nullptr, &nm));
+    PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_F32, m->fp8 ? m->q_head : m->lm_head, kv->xn, H, kv->logits, V, V, H, B, s, m->fp8 ? m->s_head : nullptr, &nm));
     pgv_prof_begin(ctx, 6, s);
     if (flags & AM_SAMPLE)
         PGV_TRY(pgv_launch_sample(kv->logits, V, B, kv->s_temp, kv->s_topk, kv->d_u, B, 1, kv->d_cur, kv->d_pos, kv->d_step, kv->d_hist, kv->max_seq, kv->d_done,
@@ -448,14 +448,14 @@ static int decode_enqueue(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int eos, int fla
         const LlmLayer& l = m->layers[li];
         const bool q8 = m->fp8;
         GemvNorm cons; cons.ssq_in = kv->ssq; cons.nparts_in = parts_in; cons.hidden = H; cons.eps = m->cfg.eps;
-        PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_STORE16, q8 ? l.q_wqkv : l.wqkv, kv->xn, H, kv->qkv, 3 * H, 3 * H, H, B, s, 1, q8 ? l.s_wqkv : nullptr, &cons));
+        PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_STORE16, q8 ? l.q_wqkv : l.wqkv, kv->xn, H, kv->qkv, 3 * H, 3 * H, H, B, s, q8 ? l.s_wqkv : nullptr, &cons));
         PGV_TRY(pgv_launch_decode_attn(ctx, m->dtype, kv->qkv, kv->d_pos, m->rope, kv->Kc[li], kv->Vc[li], kv->ao, B, H, heads, kv->max_seq, kv_bytes, s));
         GemvNorm prod; prod.gamma = l.post_g; prod.xg = kv->xn; prod.ssq_out = kv->ssq;
-        PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_RESIDNORM, q8 ? l.q_wo : l.wo, kv->ao, H, kv->resid, H, H, H, B, s, 1, q8 ? l.s_wo : nullptr, &prod));
+        PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_RESIDNORM, q8 ? l.q_wo : l.wo, kv->ao, H, kv->resid, H, H, H, B, s, q8 ? l.s_wo : nullptr, &prod));
         cons.nparts_in = nparts;
-        PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_SWIGLU, q8 ? l.q_wgu : l.wgu, kv->xn, H, kv->act, I, 2 * I, H, B, s, 1, q8 ? l.s_wgu : nullptr, &cons));
+        PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_SWIGLU, q8 ? l.q_wgu : l.wgu, kv->xn, H, kv->act, I, 2 * I, H, B, s, q8 ? l.s_wgu : nullptr, &cons));
         prod.gamma = li + 1 < L ? m->layers[li + 1].in_g : m->norm_g;
-        PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_RESIDNORM, q8 ? l.q_wdown : l.wdown, kv->act, I, kv->resid, H, H, I, B, s, 1, q8 ? l.s_wdown : nullptr, &prod));
+        PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_RESIDNORM, q8 ? l.q_wdown : l.wdown, kv->act, I, kv->resid, H, H, I, B, s, q8 ? l.s_wdown : nullptr, &prod));
         parts_in = nparts;
     }
     PGV_TRY(lm_head_and_pick(ctx, m, kv, B, eos, flags, s, parts_in));

@@ -7,6 +7,7 @@
 //   decode_attn    : RoPE + cache append + single-query attention over the cache (flash-decoding style)
 //   argmax         : greedy token + per-sequence bookkeeping (position, step, EOS stickiness) on the device
 #include <stdlib.h>
+#include <type_traits>
 
 #include "pgv_common.h"
 
@@ -243,10 +244,10 @@ __global__ __launch_bounds__(256) void prefill_attn_kernel(PrefillAttnArgs p) {
 // decode GEMV on MFMA: y[b, n] = sum_k x[b, k] W[n, k], B <= 16.
 // W is stored in the fragment-blocked layout (weights.h): block (n/16, k/32) is the 1 KiB a wave loads as ONE
 // v_mfma_f32_16x16x32 A fragment, so every wave-load is a single contiguous, fully coalesced 1 KiB burst.
-// Workgroup = 8 waves, owns TILES row blocks; wave w takes k-steps w, w+8, ... (adjacent KiBs of the same row block).
+// Workgroup = NW waves, owns TL row blocks; wave w takes the 64-column groups w, w+NW, ... (adjacent 2 KiB of the same row block).
 // B operand = x fragment (lane: batch l&15, k (l>>4)*8..+8) served by L2.  Partial 16x16 tiles are reduced through LDS.
 // ---------------------------------------------------------------------------------------------
-enum { GV_STORE16 = 0, GV_RESID = 1, GV_SWIGLU = 2, GV_F32 = 3, GV_PART = 4, GV_RESIDNORM = 5 };
+enum { GV_STORE16 = 0, GV_RESID = 1, GV_SWIGLU = 2, GV_F32 = 3, GV_RESIDNORM = 5 };
 
 // Buffer descriptor over `bytes` bytes at `base` from provably wave-uniform inputs (cdna_hip_programming.md T20): lanes whose voffset lies outside
 // the range are dropped by the hardware -- no memory request, the result is 0.
@@ -266,7 +267,6 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t gv_make_rsrc(const void* base,
 struct GemvArgs {
     const char* W; const char* x; char* out;
     int N, K, B, ldx, ldo;
-    int kb_per;     // k-blocks (of 32) per split; gridDim.y splits write fp32 partials [split][B][ldo] in GV_PART mode
     const float* wscale;   // W8 = true: per-row power-of-two scales of the fp8 matrix (fp8.hip)
     // consumer side of the folded RMSNorm (null ssq_in: plain GEMV)
     const float* ssq_in; int nparts_in; float inv_h, eps;      // ssq_in [nparts_in][16]
@@ -299,12 +299,21 @@ __device__ __forceinline__ typename T::v8 fp8x8_to_v8(unsigned lo, unsigned hi) 
 }
 
 // NW = waves per workgroup (the K split inside a workgroup).  8 everywhere except the residual producers, which cannot split K across
-// workgroups any more (the workgroup that owns 16 output rows must see their complete sums to emit xg and the sum of squares) and use 16
-// waves instead, so that a CU still has 16 waves' worth of weight loads in flight with one workgroup per CU.
+// workgroups (the workgroup that owns 16 output rows must see their complete sums to emit xg and the sum of squares) and use 16 waves
+// instead, so that a CU still has 16 waves' worth of weight loads in flight with one workgroup per CU.
 // TL = row blocks of 16 per workgroup.  Every row block of a workgroup multiplies the SAME x fragments, so the activation loads -- which are
 // re-read by every workgroup and cost as many requests on the CU's load path as the weights of ONE row block -- are shared: 2 for gate/up
 // (the SiLU pair), 3 for qkv when the row-block count divides (7B: 768 = 3 x 256 workgroups, one per CU), 1 otherwise.
-template <typename T, int MODE, bool W8, int NW, int TL = (MODE == GV_SWIGLU ? 2 : 1)>
+// PU = 64-column groups per register buffer.  The weight stream is software-pipelined over two buffers: the loads of batch i+1 are issued
+// before the MFMAs of batch i, so a wave always has one or two batches in flight (no round trip with an empty memory pipe between batches,
+// which is what the launches with ONE workgroup per CU -- the producers, qkv with TL = 3 -- cannot hide behind another workgroup).
+// X2 (B <= 8 only): the x fragments of BOTH k-blocks of a 64-column group come from one wave-load.  An MFMA B operand has 16 batch columns;
+// with at most 8 sequences the lanes of columns 8..15 are free, so they fetch the second k-block of columns 0..7 -- per batch row the wave
+// then reads one full 128-byte line instead of two half lines in two instructions -- and a row_ror:8 DPP move hands it to the lanes that feed
+// the second MFMA.  (Columns >= 8 of either operand then hold the other half's data: they only reach output columns that are never stored.)
+// The activations are re-read from L2 by every workgroup: this halves their requests on the CU's load path and in the L2, which is what the
+// fp8 GEMVs (half the weight requests, the same x requests) were bound by: 3.5 -> 4.4 TB/s of fp8 bytes; 16-bit weights: +0.7 %.
+template <typename T, int MODE, bool W8, int NW, int TL, int PU, bool X2>
 __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
     constexpr int TILES = TL;
     __shared__ f32x4_t red[NW][TILES][64];
@@ -353,112 +362,88 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
     f32x4_t acc[TILES];
 #pragma unroll
     for (int t = 0; t < TILES; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    if constexpr (W8) {
-        // k is walked in blocks of 64 (one 16-byte load = two MFMA k-blocks); kb_per counts 32-blocks and is even here
-        const int k64 = p.K >> 6;
+    {
+        // groups (64 columns) j_lo + w + NW * g, g = 0 .. : batch b holds g = b * PU .. b * PU + PU - 1.  Every batch but the last is complete
+        // for every wave (the waves' group counts differ by at most one); in the last batch, entries past the end re-read the last valid
+        // block (an L2 hit) against an all-zero x fragment, which adds exact zeros -- no predicated loads (predicated loads would make hipcc serialise the whole batch: a vmcnt(0) per load).
+        const int kb_end = kblocks;
+        const int j_end = (kb_end + 1) >> 1;                      // the last group may hold a single 32-block (16-bit weights; fp8 needs K % 64 == 0)
+        constexpr int j_lo = 0;
+        const int gpw = (j_end - j_lo + NW - 1) / NW;
+        const int nb = (gpw + PU - 1) / PU;
+        using wreg_t = typename std::conditional<W8, u32x4_t, typename T::v8>::type;
+        constexpr int WH = W8 ? 1 : 2;                            // weight loads per group and row block
         const char* wp[TILES];
 #pragma unroll
-        for (int t = 0; t < TILES; ++t) wp[t] = p.W + ((size_t)rb[t] * k64) * 1024 + lane * 16;
-        constexpr int U = (TILES >= 2) ? 4 : 8;
-        const int j_end = min(k64, (int)(blockIdx.y + 1) * (p.kb_per >> 1));
-        int j = blockIdx.y * (p.kb_per >> 1) + w;
-        for (; j + NW * (U - 1) < j_end; j += NW * U) {
-            u32x4_t wr[U][TILES];
-            typename T::v8 xf[U][2];
+        for (int t = 0; t < TILES; ++t) wp[t] = p.W + ((size_t)rb[t] * (W8 ? (p.K >> 6) : kblocks)) * 1024 + lane * 16;
+        constexpr int XH = X2 ? 1 : 2;                            // x loads per group
+        const unsigned xvo2 = (l15 & 7) < p.B ? (unsigned)(((size_t)(l15 & 7) * p.ldx + (l15 >> 3) * 32 + kg * 8) * 2) : 0x80000000u;
+        auto load = [&](wreg_t (&wf)[PU][WH][TILES], typename T::v8 (&xf)[PU][XH], int b) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-#pragma unroll
-                for (int t = 0; t < TILES; ++t) wr[u][t] = __builtin_nontemporal_load((const u32x4_t*)(wp[t] + (size_t)(j + NW * u) * 1024));
-                xf[u][0] = xload((size_t)(2 * (j + NW * u)));
-                xf[u][1] = xload((size_t)(2 * (j + NW * u) + 1));
-            }
-            __builtin_amdgcn_sched_barrier(0);      // every load of the batch is in flight before the first use (hipcc otherwise sinks
-                                                    // each load to its MFMA to save registers and waits vmcnt(0) per k-block)
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int t = 0; t < TILES; ++t) {
-                    acc[t] = T::mfma16(fp8x8_to_v8<T>(wr[u][t][0], wr[u][t][1]), xf[u][0], acc[t]);
-                    acc[t] = T::mfma16(fp8x8_to_v8<T>(wr[u][t][2], wr[u][t][3]), xf[u][1], acc[t]);
-                }
-        }
-        if (j < j_end) {
-            // Ragged tail (11008 / 2 splits / 8 waves = 10.75 groups per wave): ONE more branch-free batch. Groups past the end re-read the
-            // last valid group (an L2 hit) against an all-zero x fragment, which adds exact zeros; predicated loads would make hipcc
-            // serialise the whole batch (a vmcnt(0) per load), and one load per round trip is what this replaces.
-            u32x4_t wr[U - 1][TILES];
-            typename T::v8 xf[U - 1][2];
-#pragma unroll
-            for (int u = 0; u < U - 1; ++u) {
-                const int jj = min(j + NW * u, j_end - 1);
-#pragma unroll
-                for (int t = 0; t < TILES; ++t) wr[u][t] = __builtin_nontemporal_load((const u32x4_t*)(wp[t] + (size_t)jj * 1024));
-                xf[u][0] = xload((size_t)(2 * jj));
-                xf[u][1] = xload((size_t)(2 * jj + 1));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < U - 1; ++u) {
-                const bool live = j + NW * u < j_end;
-                const typename T::v8 z = {};
-#pragma unroll
-                for (int t = 0; t < TILES; ++t) {
-                    acc[t] = T::mfma16(fp8x8_to_v8<T>(wr[u][t][0], wr[u][t][1]), live ? xf[u][0] : z, acc[t]);
-                    acc[t] = T::mfma16(fp8x8_to_v8<T>(wr[u][t][2], wr[u][t][3]), live ? xf[u][1] : z, acc[t]);
-                }
-            }
-        }
-    } else {
-        // Same k order as the fp8 branch (wave w takes the 64-column groups w, w+NW, ...; inside a group the two 32-blocks in order), so
-        // the two kernels accumulate identically and the fp8 path is bit-equal to the 16-bit path on the dequantised matrix.
-        const char* wp[TILES];
-#pragma unroll
-        for (int t = 0; t < TILES; ++t) wp[t] = p.W + ((size_t)rb[t] * kblocks) * 1024 + lane * 16;
-        constexpr int U = (TILES >= 2) ? 2 : 4;
-        const int kb_end = min(kblocks, (int)(blockIdx.y + 1) * p.kb_per);       // 32-blocks; kb_per is even
-        const int j_end = (kb_end + 1) >> 1;                                     // 64-groups (the last may hold one 32-block)
-        int j = ((blockIdx.y * p.kb_per) >> 1) + w;
-        for (; j + NW * (U - 1) < j_end && 2 * (j + NW * (U - 1)) + 1 < kb_end; j += NW * U) {
-            typename T::v8 wf[U][2][TILES], xf[U][2];
-#pragma unroll
-            for (int u = 0; u < U; ++u)
+            for (int u = 0; u < PU; ++u) {
+                const int g = j_lo + w + NW * (b * PU + u);
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const size_t kb = (size_t)(2 * (j + NW * u) + h);
+                    const int kb = min(2 * g + h, kb_end - 1);
+                    if (!W8 || h == 0) {
 #pragma unroll
-                    for (int t = 0; t < TILES; ++t) wf[u][h][t] = __builtin_nontemporal_load((const typename T::v8*)(wp[t] + kb * 1024));
-                    xf[u][h] = xload(kb);
+                        for (int t = 0; t < TILES; ++t)
+                            wf[u][W8 ? 0 : h][t] = __builtin_nontemporal_load((const wreg_t*)(wp[t] + (size_t)(W8 ? min(g, j_end - 1) : kb) * 1024));
+                    }
+                    if constexpr (!X2) xf[u][h] = xload((size_t)kb);
+                    else if (h == 0)
+                        xf[u][0] = __builtin_bit_cast(typename T::v8, __builtin_amdgcn_raw_buffer_load_b128(xrs, xvo2 + (unsigned)min(g, j_end - 1) * 128u, 0, 0));
                 }
-            __builtin_amdgcn_sched_barrier(0);      // as above: the whole batch in flight before the first MFMA
+            }
+        };
+        auto mma = [&](wreg_t (&wf)[PU][WH][TILES], typename T::v8 (&xf)[PU][XH], int b, bool last) {
 #pragma unroll
-            for (int u = 0; u < U; ++u)
+            for (int u = 0; u < PU; ++u) {
+                const int g = j_lo + w + NW * (b * PU + u);
+                typename T::v8 xv[2];
+                xv[0] = xf[u][0];
+                if constexpr (X2) {
+                    const u32x4_t r = __builtin_bit_cast(u32x4_t, xf[u][0]);
+                    u32x4_t q;
 #pragma unroll
-                for (int t = 0; t < TILES; ++t) {
-                    acc[t] = T::mfma16(wf[u][0][t], xf[u][0], acc[t]);
-                    acc[t] = T::mfma16(wf[u][1][t], xf[u][1], acc[t]);
-                }
-        }
-        if (j < j_end) {                            // ragged tail as in the fp8 branch; here the last group may also hold a single 32-block
-            typename T::v8 wf[U][2][TILES], xf[U][2];
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const size_t kb = (size_t)min(2 * (j + NW * u) + h, kb_end - 1);
-#pragma unroll
-                    for (int t = 0; t < TILES; ++t) wf[u][h][t] = __builtin_nontemporal_load((const typename T::v8*)(wp[t] + kb * 1024));
-                    xf[u][h] = xload(kb);
-                }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const bool live = 2 * (j + NW * u) + h < kb_end;
+                    for (int e = 0; e < 4; ++e) q[e] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)r[e], 0x128, 0xF, 0xF, true);   // row_ror:8
+                    xv[1] = __builtin_bit_cast(typename T::v8, q);
+                } else xv[1] = xf[u][XH - 1];
+                if (last) {
                     const typename T::v8 z = {};
 #pragma unroll
-                    for (int t = 0; t < TILES; ++t) acc[t] = T::mfma16(wf[u][h][t], live ? xf[u][h] : z, acc[t]);
+                    for (int h = 0; h < 2; ++h) xv[h] = (2 * g + h >= kb_end) ? z : xv[h];
                 }
+#pragma unroll
+                for (int t = 0; t < TILES; ++t)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        if constexpr (W8) acc[t] = T::mfma16(fp8x8_to_v8<T>(wf[u][0][t][2 * h], wf[u][0][t][2 * h + 1]), xv[h], acc[t]);
+                        else acc[t] = T::mfma16(wf[u][h][t], xv[h], acc[t]);
+                    }
+            }
+        };
+        wreg_t wa[PU][WH][TILES], wb[PU][WH][TILES];
+        typename T::v8 xa[PU][XH], xb[PU][XH];
+        load(wa, xa, 0);
+        int i = 0;
+        for (; i + 2 < nb; i += 2) {
+            load(wb, xb, i + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(wa, xa, i, false);
+            __builtin_amdgcn_sched_barrier(0);
+            load(wa, xa, i + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(wb, xb, i + 1, false);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (nb - i == 2) {
+            load(wb, xb, i + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(wa, xa, i, false);
+            mma(wb, xb, i + 1, true);
+        } else {
+            mma(wa, xa, i, true);
         }
     }
 #pragma unroll
@@ -542,8 +527,6 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
     } else if constexpr (MODE == GV_RESID) {
         f32x4_t* rp = (f32x4_t*)(p.out + ((size_t)b * p.ldo + n0) * 4);
         *rp = *rp + tot[0];
-    } else if constexpr (MODE == GV_PART) {
-        *(f32x4_t*)((float*)p.out + ((size_t)blockIdx.y * p.B + b) * p.ldo + n0) = tot[0];
     } else {
         float* op = (float*)p.out + (size_t)b * p.ldo + n0;
 #pragma unroll
@@ -985,7 +968,7 @@ int pgv_launch_embed_tok_norm(int dtype, const int* tok, const void* embed, floa
 }
 
 int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void* x, int ldx, void* out, int ldo, int N, int K, int B, hipStream_t s,
-                    int splits, const float* wscale, const GemvNorm* norm) {
+                    const float* wscale, const GemvNorm* norm) {
     PGV_CHECK(B >= 1 && B <= 16, "gemv: batch %d outside [1,16]", B);
     PGV_CHECK(K % 32 == 0, "gemv: K=%d must be a multiple of 32", K);
     const bool w8 = wscale != nullptr;                  // W is the fp8 blocked copy (fp8.hip) with per-row scales
@@ -997,36 +980,38 @@ int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void
         a.gamma = norm->gamma; a.xg = (char*)norm->xg; a.ssq_out = norm->ssq_out; a.amax_val = norm->amax_val; a.amax_idx = norm->amax_idx;
         PGV_CHECK(norm->nparts_in * 4 <= 3 * 8 * 64, "gemv: %d sum-of-squares partials exceed what a consumer workgroup loads (hidden <= 6144)", norm->nparts_in);
     }
-    PGV_CHECK(splits >= 1 && (splits == 1 || mode == GV_PART), "gemv: split-K needs the partial-output mode");
     PGV_CHECK(mode != GV_RESIDNORM || (a.gamma && a.xg && a.ssq_out), "gemv: the residual+norm producer needs gamma / xg / ssq_out");
-    a.kb_per = ((((K / 32) + splits - 1) / splits) + 1) & ~1;      // 32-blocks per split, even: splits fall on 64-column boundaries
     if (w8) PGV_CHECK(K % 64 == 0, "gemv fp8: K=%d must be a multiple of 64", K);
     int grid;
     // W must be in the fragment-blocked layout with its row count padded to a multiple of 16 (zero rows)
     if (mode == GV_SWIGLU) { PGV_CHECK(N % 64 == 0, "gemv swiglu: N=%d must be a multiple of 64", N); grid = N / 32; }
     else { if (mode != GV_F32) PGV_CHECK(N % 16 == 0, "gemv: N=%d must be a multiple of 16", N); grid = (N + 15) / 16; }
     pgv_prof_begin(ctx, 3, s);
-#define PGV_GEMV(MODE_, W8_, NW_) PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gemv_mfma_kernel<T, MODE_, W8_, NW_>), dim3(grid, splits), dim3(NW_ * 64), 0, s, a))
-#define PGV_GEMV2(MODE_, NW_) do { if (w8) PGV_GEMV(MODE_, true, NW_); else PGV_GEMV(MODE_, false, NW_); } while (0)
-#define PGV_GEMV_TL3(W8_) PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gemv_mfma_kernel<T, GV_STORE16, W8_, 8, 3>), dim3(grid / 3, 1), dim3(512), 0, s, a))
-    static int tl3 = -1;
+    // register-buffer depth: an fp8 group is one 16-byte load per lane and row block, a 16-bit group two -- the fp8 variants buffer twice as
+    // many groups for the same bytes in flight
+#define PGV_GEMV_X(MODE_, NW_, TL_, PU16_, PU8_, X2_, GRID_) do { \
+        if (w8) PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gemv_mfma_kernel<T, MODE_, true, NW_, TL_, PU8_, X2_>), dim3(GRID_), dim3(NW_ * 64), 0, s, a)); \
+        else PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gemv_mfma_kernel<T, MODE_, false, NW_, TL_, PU16_, X2_>), dim3(GRID_), dim3(NW_ * 64), 0, s, a)); } while (0)
+#define PGV_GEMV(MODE_, NW_, TL_, PU16_, PU8X_, PU8_, GRID_) do { \
+        if (x2) PGV_GEMV_X(MODE_, NW_, TL_, PU16_, PU8X_, true, GRID_); else PGV_GEMV_X(MODE_, NW_, TL_, PU16_, PU8_, false, GRID_); } while (0)
+    static int tl3 = -1, x2env = -1;
     if (tl3 < 0) { const char* e = getenv("PGV_GEMV_TL3"); tl3 = (e && e[0] == '0') ? 0 : 1; }
+    if (x2env < 0) { const char* e = getenv("PGV_GEMV_X2"); x2env = (e && e[0] == '0') ? 0 : 1; }
+    const bool x2 = x2env && B <= 8;
     switch (mode) {
         case GV_STORE16:
             // three row blocks per workgroup when that puts at most ~one workgroup on every CU and nothing is left over (7B qkv: 768 -> 256)
-            if (tl3 && grid % 3 == 0 && grid / 3 <= ctx->num_cu && grid / 3 >= ctx->num_cu / 2) { if (w8) PGV_GEMV_TL3(true); else PGV_GEMV_TL3(false); }
-            else PGV_GEMV2(GV_STORE16, 8);
+            if (tl3 && grid % 3 == 0 && grid / 3 <= ctx->num_cu && grid / 3 >= ctx->num_cu / 2) PGV_GEMV(GV_STORE16, 8, 3, 1, 2, 2, grid / 3);
+            else PGV_GEMV(GV_STORE16, 8, 1, 2, 4, 4, grid);
             break;
-        case GV_RESID: PGV_GEMV2(GV_RESID, 8); break;
-        case GV_SWIGLU: PGV_GEMV2(GV_SWIGLU, 8); break;
-        case GV_F32: PGV_GEMV2(GV_F32, 8); break;
-        case GV_PART: PGV_GEMV2(GV_PART, 8); break;
-        case GV_RESIDNORM: PGV_GEMV2(GV_RESIDNORM, 16); break;
+        case GV_RESID: PGV_GEMV(GV_RESID, 8, 1, 2, 4, 4, grid); break;
+        case GV_SWIGLU: PGV_GEMV(GV_SWIGLU, 8, 2, 1, 2, 2, grid); break;
+        case GV_F32: PGV_GEMV(GV_F32, 8, 1, 2, 4, 4, grid); break;
+        case GV_RESIDNORM: PGV_GEMV(GV_RESIDNORM, 16, 1, 2, 4, 2, grid); break;     // 16 waves: 128 VGPRs per wave bound the un-merged fp8 variant to 2
         default: pgv_set_error("gemv: bad mode %d", mode); return PGV_EINVAL;
     }
-#undef PGV_GEMV_TL3
-#undef PGV_GEMV2
 #undef PGV_GEMV
+#undef PGV_GEMV_X
     pgv_prof_end(ctx, 3, s, 2.0 * B * (double)N * K, (w8 ? 1.0 : 2.0) * (double)N * K);
     return PGV_OK;
 }
@@ -1078,7 +1063,7 @@ extern "C" int pgv_gemv(pgv_ctx* ctx, int dtype, int mode, const void* d_W, cons
                         void* stream) {
     PGV_CHECK(ctx && d_W && d_x && d_out, "pgv_gemv: null argument");
     PGV_CHECK(mode >= 0 && mode <= 3, "pgv_gemv: mode %d outside [0,3]", mode);
-    return pgv_launch_gemv(ctx, dtype, mode, d_W, d_x, ldx, d_out, ldo, N, K, B, (hipStream_t)stream, 1, nullptr, nullptr);
+    return pgv_launch_gemv(ctx, dtype, mode, d_W, d_x, ldx, d_out, ldo, N, K, B, (hipStream_t)stream, nullptr, nullptr);
 }
 
 #include "weights.h"
@@ -1093,5 +1078,5 @@ extern "C" int pgv_gemv_fp8(pgv_ctx* ctx, int dtype, int mode, const void* d_W8,
                             int K, int B, void* stream) {
     PGV_CHECK(ctx && d_W8 && d_scales && d_x && d_out, "pgv_gemv_fp8: null argument");
     PGV_CHECK(mode >= GV_STORE16 && mode <= GV_F32, "pgv_gemv_fp8: mode %d outside [0,3]", mode);
-    return pgv_launch_gemv(ctx, dtype, mode, d_W8, d_x, ldx, d_out, ldo, N, K, B, (hipStream_t)stream, 1, d_scales, nullptr);
+    return pgv_launch_gemv(ctx, dtype, mode, d_W8, d_x, ldx, d_out, ldo, N, K, B, (hipStream_t)stream, d_scales, nullptr);
 }
