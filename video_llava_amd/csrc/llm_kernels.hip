@@ -298,9 +298,10 @@ __device__ __forceinline__ typename T::v8 fp8x8_to_v8(unsigned lo, unsigned hi) 
     return r;
 }
 
-// NW = waves per workgroup (the K split inside a workgroup).  8 everywhere except the residual producers, which cannot split K across
-// workgroups (the workgroup that owns 16 output rows must see their complete sums to emit xg and the sum of squares) and use 16 waves
-// instead, so that a CU still has 16 waves' worth of weight loads in flight with one workgroup per CU.
+// NW = waves per workgroup (the K split inside a workgroup): 8.  The residual producers cannot split K across workgroups (the workgroup that
+// owns 16 output rows must see their complete sums to emit xg and the sum of squares), so o_proj / down_proj run 256 workgroups = one per CU
+// with 8 waves; the pipelined weight stream below keeps enough loads in flight for that (down_proj 16.4 us; a 16-wave variant, needed
+// before the stream was pipelined, takes 19.3 us: twice the LDS partials and 12 % dead tail loads at 10.75 groups per wave).
 // TL = row blocks of 16 per workgroup.  Every row block of a workgroup multiplies the SAME x fragments, so the activation loads -- which are
 // re-read by every workgroup and cost as many requests on the CU's load path as the weights of ONE row block -- are shared: 2 for gate/up
 // (the SiLU pair), 3 for qkv when the row-block count divides (7B: 768 = 3 x 256 workgroups, one per CU), 1 otherwise.
@@ -602,7 +603,6 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const typename T::
     constexpr int KPR = NW * 8;                        // keys per round: NW waves x 4 slots x 2 states
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int h = blockIdx.x, b = blockIdx.y;
-    const int pos = pos_arr[b];
     const typename T::elem* q = qkv + (size_t)b * 3 * H + h * HD;
     const typename T::elem* k = q + H;
     const typename T::elem* v = q + 2 * H;
@@ -610,21 +610,29 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const typename T::
     typename T::elem* vcache = Vc + ((size_t)b * heads + h) * max_seq * HD;
     const int slot = lane >> 4, dc = lane & 15;
 
-    // The first DEPTH rounds of K / V loads go out before anything else (they need only `pos`): the query's RoPE below -- two L2 round
-    // trips for the rope table and q -- runs while they are in flight instead of in front of them.  The cache is streamed once per token
-    // (2.4 GB per token step at 8 sequences: no reuse in L2 / Infinity Cache), hence non-temporal loads like the GEMVs' weights.
-    const int n_keys = pos;                            // cached keys; the fresh key (index pos) is handled from registers below
+    // The first DEPTH rounds of K / V loads go out before anything else -- before `pos` has even arrived: their addresses depend only on
+    // kernel arguments (rows up to max_seq - 1 exist; rows >= pos hold stale or unwritten data and are masked in update()), so the stream
+    // starts without the L2 round trip of the position load in front of it, and the query's RoPE below -- two more round trips for the rope
+    // table and q -- runs while they are in flight.  The cache is streamed once per token (2.4 GB per token step at 8 sequences: no reuse
+    // in L2 / Infinity Cache), hence non-temporal loads like the GEMVs' weights.
     const int key0 = w * 4 + slot;
     // DEPTH rounds of KPR keys are kept in flight per workgroup (DEPTH x 4 x 16-B loads per lane)
     constexpr int DEPTH = NW == 8 ? 4 : 2;
     typename T::v8 kq[DEPTH][2], vq[DEPTH][2];
-    auto load = [&](int key, typename T::v8& kk_, typename T::v8& vv_) {
-        const int kc = max(0, min(key, n_keys - 1));   // clamped rows are masked below
+    auto load_row = [&](int kc, typename T::v8& kk_, typename T::v8& vv_) {
         kk_ = __builtin_nontemporal_load((const typename T::v8*)(kcache + (size_t)kc * HD + dc * 8));
         vv_ = __builtin_nontemporal_load((const typename T::v8*)(vcache + (size_t)kc * HD + dc * 8));
     };
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) { load(key0 + KPR * d, kq[d][0], vq[d][0]); load(key0 + KPR * d + KPR / 2, kq[d][1], vq[d][1]); }
+    for (int d = 0; d < DEPTH; ++d) {
+        load_row(min(key0 + KPR * d, max_seq - 1), kq[d][0], vq[d][0]);
+        load_row(min(key0 + KPR * d + KPR / 2, max_seq - 1), kq[d][1], vq[d][1]);
+    }
+    const typename T::v8 q_own = *(const typename T::v8*)(q + dc * 8), q_oth = *(const typename T::v8*)(q + (dc ^ 8) * 8);     // needs no position either
+    __builtin_amdgcn_sched_barrier(0);                 // keeps the (scalar) position load and everything that hangs off it behind the loads above
+    const int pos = pos_arr[b];
+    const int n_keys = pos;                            // cached keys; the fresh key (index pos) is handled from registers below
+    auto load = [&](int key, typename T::v8& kk_, typename T::v8& vv_) { load_row(max(0, min(key, n_keys - 1)), kk_, vv_); };   // clamped rows are masked below
 
     // rotate-half RoPE on this lane's 8 dims d = dc*8 + e of a 128-wide row x: d < 64: x[d] c[d] - x[d+64] s[d];  d >= 64: x[d] c[d-64] + x[d-64] s[d-64]
     // (values rounded to the activation dtype like the prefill path writes them)
@@ -632,13 +640,15 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const typename T::
     float cs_c[8], cs_s[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { const float2 cs = rope[(size_t)pos * 64 + j0 + e]; cs_c[e] = cs.x; cs_s[e] = dc < 8 ? -cs.y : cs.y; }
-    auto rotated = [&](const typename T::elem* x, float (&r)[8]) {
-        const typename T::v8 own = *(const typename T::v8*)(x + dc * 8), oth = *(const typename T::v8*)(x + (dc ^ 8) * 8);
+    auto rotate = [&](const typename T::v8& own, const typename T::v8& oth, float (&r)[8]) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) r[e] = (float)T::from_f32((float)own[e] * cs_c[e] + (float)oth[e] * cs_s[e]);
     };
+    auto rotated = [&](const typename T::elem* x, float (&r)[8]) {
+        rotate(*(const typename T::v8*)(x + dc * 8), *(const typename T::v8*)(x + (dc ^ 8) * 8), r);
+    };
     float qr[8];
-    rotated(q, qr);
+    rotate(q_own, q_oth, qr);
 #pragma unroll
     for (int e = 0; e < 8; ++e) qr[e] *= scale_log2e;
 
@@ -1007,7 +1017,7 @@ int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void
         case GV_RESID: PGV_GEMV(GV_RESID, 8, 1, 2, 4, 4, grid); break;
         case GV_SWIGLU: PGV_GEMV(GV_SWIGLU, 8, 2, 1, 2, 2, grid); break;
         case GV_F32: PGV_GEMV(GV_F32, 8, 1, 2, 4, 4, grid); break;
-        case GV_RESIDNORM: PGV_GEMV(GV_RESIDNORM, 16, 1, 2, 4, 2, grid); break;     // 16 waves: 128 VGPRs per wave bound the un-merged fp8 variant to 2
+        case GV_RESIDNORM: PGV_GEMV(GV_RESIDNORM, 8, 1, 2, 4, 4, grid); break;
         default: pgv_set_error("gemv: bad mode %d", mode); return PGV_EINVAL;
     }
 #undef PGV_GEMV
