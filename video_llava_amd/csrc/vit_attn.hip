@@ -233,15 +233,26 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(AttnArgs p) {
         const float ltot = lrun + __shfl_xor(lrun, 32, 64);
         const float inv = 1.0f / ltot;
         const int q = qb * 32 + l31;
+        // Output row q lives in the lane pair (q, q + 32): 4 consecutive d per accumulator group, alternating between the two lanes.  Two
+        // v_permlane32_swap per group pair hand each lane 8 consecutive d, so a row is written as 32 contiguous bytes per store instruction
+        // (4 stores of 16 B per lane instead of 8 of 8 B: the 16-byte pieces were a quarter of the kernel's time on the L2 write path).
+        u32x4_t piece[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const u32x2_t a = pack4<T>(o[j][8 * m + 0] * inv, o[j][8 * m + 1] * inv, o[j][8 * m + 2] * inv, o[j][8 * m + 3] * inv);      // group 2m:     d = 16m + 4hi + 0..3
+                const u32x2_t b = pack4<T>(o[j][8 * m + 4] * inv, o[j][8 * m + 5] * inv, o[j][8 * m + 6] * inv, o[j][8 * m + 7] * inv);      // group 2m + 1: d = 16m + 8 + 4hi + 0..3
+                const auto r0 = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
+                const auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
+                piece[j][m] = u32x4_t{r0[0], r1[0], r0[1], r1[1]};           // lanes 0-31: d = 16m .. 16m+7; lanes 32-63: d = 16m+8 .. 16m+15
+            }
         if (q < N) {
             char* orow = p.out + ((row0 + q) * p.ldo + h * HD) * 2;
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int d = j * 32 + 8 * g + 4 * hi;
-                    *(u32x2_t*)(orow + d * 2) = pack4<T>(o[j][g * 4 + 0] * inv, o[j][g * 4 + 1] * inv, o[j][g * 4 + 2] * inv, o[j][g * 4 + 3] * inv);
-                }
+                for (int m = 0; m < 2; ++m) *(u32x4_t*)(orow + (j * 32 + 16 * m + 8 * hi) * 2) = piece[j][m];
         }
     }
 }
