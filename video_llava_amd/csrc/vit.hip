@@ -35,6 +35,7 @@ struct pgv_vit {
     size_t blob_bytes = 0;
     void* patch_w;
     float *cls, *pos, *pre_g, *pre_b;
+    float* ones;                   // [hidden] of 1.0f: the "next gamma" of the last executed layer, whose 16-bit operand copy IS the hidden state returned
     std::vector<VitLayer> layers;
     std::set<std::string> loaded;
     int expected = 0;
@@ -57,7 +58,7 @@ extern "C" int pgv_vit_create(pgv_ctx* ctx, const pgv_vit_config* cfg, int dtype
     const size_t C = cfg->hidden, I = cfg->inter, L = cfg->layers;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += pgv_align(bytes); return o; };
-    const size_t o_patch = take(C * v->Kp * 2), o_cls = take(C * 4), o_pos = take((size_t)v->tokens * C * 4), o_pg = take(C * 4), o_pb = take(C * 4);
+    const size_t o_patch = take(C * v->Kp * 2), o_cls = take(C * 4), o_pos = take((size_t)v->tokens * C * 4), o_pg = take(C * 4), o_pb = take(C * 4), o_ones = take(C * 4);
     struct LO { size_t ln1g, ln1b, ln2g, ln2b, wqkv, wo, w1, w2, bqkv, bo, b1, b2, sqkv, b2qkv, sfc1, b2fc1; };
     std::vector<LO> lo(L);
     for (size_t i = 0; i < L; ++i) {
@@ -70,7 +71,12 @@ extern "C" int pgv_vit_create(pgv_ctx* ctx, const pgv_vit_config* cfg, int dtype
     if (e != hipSuccess) { delete v; pgv_set_error("pgv_vit_create: hipMalloc(%zu MiB): %s", off >> 20, hipGetErrorString(e)); return PGV_ENOMEM; }
     v->blob_bytes = off;
     char* b = v->blob;
-    v->patch_w = b + o_patch; v->cls = (float*)(b + o_cls); v->pos = (float*)(b + o_pos); v->pre_g = (float*)(b + o_pg); v->pre_b = (float*)(b + o_pb);
+    v->patch_w = b + o_patch; v->cls = (float*)(b + o_cls); v->pos = (float*)(b + o_pos); v->pre_g = (float*)(b + o_pg); v->pre_b = (float*)(b + o_pb); v->ones = (float*)(b + o_ones);
+    {
+        std::vector<float> one(C, 1.0f);
+        e = hipMemcpy(v->ones, one.data(), C * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(v->blob); delete v; pgv_set_error("pgv_vit_create: upload: %s", hipGetErrorString(e)); return PGV_EHIP; }
+    }
     v->layers.resize(L);
     for (size_t i = 0; i < L; ++i) {
         VitLayer& l = v->layers[i];
@@ -213,7 +219,9 @@ extern "C" int pgv_vit_forward(pgv_ctx* ctx, pgv_vit* v, const void* d_pixels, i
                     PGV_TRY(pgv_launch_gemm(ctx, v->dtype, g, s));
                     PGV_TRY(pgv_launch_ln_stats(part, rowstat, M, NP, C, v->cfg.eps, s));
                 } else {
-                    g.epi = PGV_EPI_BIAS_RESID;          // the last executed layer feeds no LayerNorm
+                    // the last executed layer feeds no LayerNorm: its "operand copy" with gamma = 1 is round16(resid) -- the hidden state itself,
+                    // written straight into the caller's buffer (no cast pass over the fp32 residual); the statistics are discarded
+                    g.epi = PGV_EPI_BIAS_RESID_LNOUT; g.gnext = v->ones; g.x16 = (char*)d_hidden + (size_t)t0 * N * C * 2; g.ldx16 = C; g.stats_part = part;
                     PGV_TRY(pgv_launch_gemm(ctx, v->dtype, g, s));
                 }
                 continue;
@@ -230,7 +238,7 @@ extern "C" int pgv_vit_forward(pgv_ctx* ctx, pgv_vit* v, const void* d_pixels, i
             g = GemmArgs{}; g.A = hbuf; g.lda = I; g.W = l.w2; g.ldw = I; g.bias = l.b2; g.C = resid; g.ldc = C; g.M = M; g.N = C; g.K = I; g.epi = PGV_EPI_BIAS_RESID;
             PGV_TRY(pgv_launch_gemm(ctx, v->dtype, g, s));
         }
-        PGV_TRY(pgv_launch_cast(v->dtype, resid, (char*)d_hidden + (size_t)t0 * N * C * 2, (size_t)M * C, s));
+        if (!(fold && n_layers > 0)) PGV_TRY(pgv_launch_cast(v->dtype, resid, (char*)d_hidden + (size_t)t0 * N * C * 2, (size_t)M * C, s));
     }
     PGV_HIP(hipGetLastError());
     return PGV_OK;
