@@ -257,6 +257,17 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t gv_make_rsrc(const void* base,
     return __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 
+// Cross-row sums with gfx950's lane-swap instructions instead of ds_bpermute round trips.  Only the FIRST result of the swap is used (vdst:
+// even rows / the low half keep their value, odd rows / the high half receive the partner's -- checked on hardware, scripts/lab/permlane_swap.hip):
+// v + swap(v, v) is the pair sum in the odd rows / the high half, so after both steps the total of the four rows sits in ROW 3 (lanes 48..63).
+// (The second result would give the sum everywhere, but with one value on both operands hipcc of ROCm 7.2 reads it from the wrong register.)
+__device__ __forceinline__ float rows_sum_to_row3(float v) {
+    const unsigned a = __builtin_bit_cast(unsigned, v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_permlane16_swap(a, a, false, false)[0]);          // rows 1, 3: v1 + v0, v3 + v2
+    const unsigned b = __builtin_bit_cast(unsigned, v);
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_permlane32_swap(b, b, false, false)[0]);    // row 3: (v3 + v2) + (v1 + v0)
+}
+
 // RMSNorm is folded into the GEMVs around it (decode only; no launch of its own):
 //   producer (GV_RESIDNORM: o_proj, down_proj; also the embedding gather): r = resid + y is written back in fp32, xg = round16(r * gamma) --
 //     gamma of the norm that FOLLOWS, known statically -- is written as the 16-bit operand of the next GEMV, and the sum of r^2 over the
@@ -455,12 +466,17 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
 #pragma unroll
         for (int q = 0; q < SSQ_LD; ++q)
             if (tid + q * NW * 64 < n4) ssq_acc += ssq_ld[q];
-        // lanes with equal (lane & 3) hold the same 4 batch columns (NW * 64 is a multiple of 4): fold the wave, lanes 0..3 publish
+        // lanes with equal (lane & 3) hold the same 4 batch columns (NW * 64 is a multiple of 4): fold the wave, lanes 48..51 publish.  DPP rotations
+        // inside the rows of 16 and the gfx950 row / half swaps across them: no LDS round trips (four dependent ds_bpermute rounds sat on the
+        // tail of every consumer launch).  Fixed association per lane: deterministic.
 #pragma unroll
-        for (int o = 4; o <= 32; o <<= 1)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) ssq_acc[e] += __shfl_xor(ssq_acc[e], o, 64);
-        if (lane < 4) ssq_red[w][lane] = ssq_acc;
+        for (int e = 0; e < 4; ++e) {
+            float v = ssq_acc[e];
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));      // row_ror:4
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));      // row_ror:8
+            ssq_acc[e] = rows_sum_to_row3(v);
+        }
+        if (lane >= 48 && lane < 52) ssq_red[w][lane - 48] = ssq_acc;
     }
     __syncthreads();
     if (w != 0) return;
@@ -497,9 +513,10 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
             *(u32x2_t*)(p.xg + ((size_t)b * p.ldo + n0) * 2) = pack4<T>(r[0] * g[0], r[1] * g[1], r[2] * g[2], r[3] * g[3]);
             sq = (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
         }
-        sq += __shfl_xor(sq, 16, 64);
-        sq += __shfl_xor(sq, 32, 64);
-        if (kg == 0) p.ssq_out[(size_t)blockIdx.x * 16 + b] = sq;               // columns >= B carry 0
+        {   // sum over the four rows of 16 lanes (the 16 output rows of this workgroup) without LDS round trips
+            sq = rows_sum_to_row3(sq);
+        }
+        if (kg == 3) p.ssq_out[(size_t)blockIdx.x * 16 + b] = sq;               // columns >= B carry 0
         return;
     }
     if constexpr (MODE == GV_F32) {
