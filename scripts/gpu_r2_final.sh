@@ -3,7 +3,7 @@
 # side benches (fp8 7B / 13B, vision-only, 336 px).  Everything lands in gpurun_out/r2final/ (summaries are copied to profiles/ by hand).
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-O=gpurun_out/r2final3; mkdir -p $O
+O=gpurun_out/r2final4; mkdir -p $O
 timeout 2400 python -m pytest tests -m gpu -q -s --durations=8 > $O/pytest.log 2>&1
 tail -14 $O/pytest.log | cut -c1-200; grep -n "rel err" $O/pytest.log | cut -c1-160 | head -30
 timeout 300 python __graft_entry__.py smoke > $O/smoke.log 2>&1; tail -1 $O/smoke.log
