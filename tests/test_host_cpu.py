@@ -404,3 +404,32 @@ def test_frame_directory_front_end(tmp_path):
     with pytest.raises(ValueError, match="no image files"):
         (tmp_path / "empty").mkdir()
         fx.sample_frames(str(tmp_path / "empty"))
+
+
+def test_animated_gif_front_end(tmp_path):
+    """The TGIF runner's files are .gif: without decord they are decoded by Pillow.  Frames are sampled with get_seq_frames and must equal an
+    independent frame-by-frame decode of the same file (GIF itself is lossy: compare against the file, not against the source array)."""
+    from PIL import Image
+    from video_llava_amd import feature_extraction as fx
+    from video_llava_amd.eval import _sharded
+    from video_llava_amd.eval.model_utils import get_seq_frames
+    rng = np.random.default_rng(5)
+    src = [Image.fromarray(rng.integers(0, 256, (20, 28, 3), dtype=np.uint8)) for _ in range(120)]
+    path = tmp_path / "tumblr_x.gif"
+    src[0].save(path, save_all=True, append_images=src[1:], duration=40, loop=0)
+    with Image.open(path) as im:
+        assert im.n_frames == 120
+        ref = []
+        for i in range(120):
+            im.seek(i)
+            ref.append(np.asarray(im.convert("RGB")))
+    ref = np.stack(ref)
+    got = fx.sample_frames(str(path))
+    assert got.shape == (100, 20, 28, 3) and np.array_equal(got, ref[get_seq_frames(120, 100)])
+    small = fx.load_video(str(path), shape=(14, 14))
+    assert small.shape == (100, 14, 14, 3) and np.array_equal(small, fx.resize_nearest(got, (14, 14)))
+    # runner-side discovery: the reference's extension order first, then the decord-free forms (array, directory of frames)
+    assert _sharded.first_existing(str(tmp_path), "tumblr_x", [".gif", *_sharded.DECORD_FREE_FORMATS]) == str(path)
+    (tmp_path / "clip7").mkdir()
+    assert _sharded.first_existing(str(tmp_path), "clip7", [".mp4", *_sharded.DECORD_FREE_FORMATS]) == str(tmp_path / "clip7")
+    assert _sharded.first_existing(str(tmp_path), "absent", [".mp4", *_sharded.DECORD_FREE_FORMATS]) is None

@@ -55,12 +55,14 @@ def resize_nearest(arr: np.ndarray, shape) -> np.ndarray:
 
 
 IMAGE_EXTENSIONS = (".jpg", ".jpeg", ".png", ".bmp", ".webp")
+PIL_ANIMATED_EXTENSIONS = (".gif", ".webp", ".apng")
 
 
 def sample_frames(vis_path, num_frm=100) -> np.ndarray:
     """Up to `num_frm` uniformly sampled frames (get_seq_frames) at the source's own resolution, uint8 [k, H, W, 3].
     Sources: a video file (through `decord`, like the reference), a `.npy` array of frames, or a DIRECTORY of image files (one frame per
-    file, lexicographic order -- what `ffmpeg -i clip.mp4 frames/%06d.jpg` leaves behind): the two decord-free front ends."""
+    file, lexicographic order -- what `ffmpeg -i clip.mp4 frames/%06d.jpg` leaves behind), or an animated GIF / WebP / APNG decoded by Pillow:
+    the decord-free front ends."""
     if os.path.isdir(vis_path):
         from PIL import Image
         names = sorted(n for n in os.listdir(vis_path) if n.lower().endswith(IMAGE_EXTENSIONS))
@@ -82,7 +84,19 @@ def sample_frames(vis_path, num_frm=100) -> np.ndarray:
     try:
         from decord import VideoReader, cpu
     except ImportError as e:
-        raise RuntimeError("load_video needs the `decord` package to decode video files (or pass .npy frame arrays)") from e
+        if str(vis_path).lower().endswith(PIL_ANIMATED_EXTENSIONS):
+            # animated GIF / WebP / APNG (the TGIF runner's files) without decord: Pillow decodes them frame by frame, composited to RGB
+            from PIL import Image
+            with Image.open(vis_path) as im:
+                total = getattr(im, "n_frames", 1)
+                k = min(total, num_frm)
+                frames = []
+                for i in get_seq_frames(total, k):            # ascending: a forward-only seek pattern
+                    im.seek(int(i))
+                    frames.append(np.asarray(im.convert("RGB")))
+            return np.ascontiguousarray(np.stack(frames))
+        raise RuntimeError("load_video needs the `decord` package to decode video files (or pass .npy frame arrays, a directory of frame "
+                           "images, or an animated .gif / .webp / .apng)") from e
     vr = VideoReader(vis_path, ctx=cpu(0))
     total = len(vr)
     k = min(total, num_frm)
