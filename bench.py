@@ -7,8 +7,13 @@ One "step" = one pass of the hot path over one batch of synthetic clips resident
     `--new-tokens` tokens (EOS disabled so the work is fixed) -> answer collation (all-gather when N > 1).
 Random-init weights of the named architectures, bf16 by default (BASELINE config 2/3), synthetic data.
 
-Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched by torch.distributed.run, one rank
-per GPU; prints ONE JSON line on rank 0.  `value` = clips processed by all ranks / max-over-ranks time.
+Contract: `python bench.py --gpus N --steps K --warmup W`; one rank per GPU.  For N > 1 either the caller launches it
+under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (RANK/LOCAL_RANK/WORLD_SIZE in the
+environment), or -- when WORLD_SIZE is unset -- bench.py re-executes ITSELF under torch.distributed.run with N ranks on
+127.0.0.1 (launch_self).  Either way rank 0 prints ONE JSON line.  `value` = clips processed by all ranks / max-over-ranks
+time; for N > 1 the line carries `collective` (backend, ranks seen in the gathered answers, time of the one all-gather).
+`--dry` replaces the GPU work by a deterministic token pattern (real sharding, barriers, all-gather and JSON; gloo, no GPU):
+the CPU test of the N > 1 control flow.
 The line also carries `roofline` (dominant kernel family, measured with hipEvent pairs around every launch in a
 profiled pass on the launch stream) and, at N=1, `cpu_baseline` (the CPU oracle timed on a bounded sample).
 """
@@ -17,6 +22,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -47,6 +54,9 @@ def parse():
                     help="fp8 = BASELINE config 5: decoder matrices quantised to e4m3 (per-row power-of-two scales) for the decode weight stream")
     ap.add_argument("--workload", choices=["full", "vision"], default="full",
                     help="full = BASELINE config 3/4 (frames -> answer); vision = config 2 (ViT + pool + projector)")
+    ap.add_argument("--dry", action="store_true",
+                    help="no GPU work: every rank fills its shard's answer slots with a deterministic token pattern, then the real barrier / all-gather / "
+                         "max-over-ranks / JSON path runs over gloo -- the CPU-testable skeleton of the N > 1 run (never a performance number)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-port", action="store_true", help="additionally time this repo's own CPU oracle (reported under cpu_baseline.port)")
     ap.add_argument("--overlap-vision", action="store_true",
@@ -266,8 +276,93 @@ def cpu_baseline_port(args):
             "seconds_per_clip": clip_s}
 
 
+def launch_self(args) -> int:
+    """`python bench.py --gpus N` with no torchrun environment: start the N ranks ourselves by re-executing this file under
+    torch.distributed.run (one process per GPU, LOCAL_RANK -> device, rendezvous on 127.0.0.1 at a free port).  The ranks inherit
+    stdout, so rank 0's single JSON line is this process's output; the exit code is the launcher's."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
+
+
+def dry_pattern(idx, new_tokens, vocab):
+    """Token pattern of clip `idx` in --dry mode (a function of the GLOBAL clip index, so the collation can be checked on every rank)."""
+    return [(idx * 7919 + 31 * t + 5) % vocab for t in range(new_tokens)]
+
+
+def time_collective(parallel, toks, lens, n_global, rank, world, sync, reps=5):
+    """The one exchange step of the path, timed alone: `reps` all-gathers of the answer buffer bracketed by barriers (median, ms) and the
+    number of ranks whose slots arrived filled."""
+    import torch.distributed as dist
+    ts, answers = [], None
+    for _ in range(reps):
+        sync()
+        t0 = time.perf_counter()
+        answers = parallel.gather_answers(toks, lens, n_global, rank, world)
+        ts.append((time.perf_counter() - t0) * 1e3)
+    seen = sum(1 for r in range(world) if all(answers[i] is not None and len(answers[i]) > 0 for i in parallel.shard_indices(n_global, r, world)))
+    return {"backend": dist.get_backend() if world > 1 else None, "world_seen": seen, "gather_ms": sorted(ts)[len(ts) // 2],
+            "bytes_per_rank": int((toks.numel() + lens.numel()) * 4), "op": "all_gather_into_tensor"}, answers
+
+
+def main_dry(args):
+    """--dry: the N-rank skeleton without the GPU.  Each rank owns shard_indices(n_global, rank, world), "answers" them with dry_pattern,
+    and the real collation runs; every rank checks the gathered answers against the pattern of ALL clips."""
+    from video_llava_amd import parallel
+    rank, world, _local = parallel.init_distributed("gloo")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    B, NEW, vocab = args.clips_per_gpu, args.new_tokens, 32003
+    n_global = B * world
+    mine = parallel.shard_indices(n_global, rank, world)
+    dev = torch.device("cpu")
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+
+    def step():
+        toks = torch.tensor([dry_pattern(i, NEW, vocab) for i in mine], dtype=torch.int32, device=dev)
+        lens = torch.full((len(mine),), NEW, dtype=torch.int32, device=dev)
+        return parallel.gather_answers(toks, lens, n_global, rank, world), toks, lens
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        answers, toks, lens = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt[0])
+    for i in range(n_global):
+        assert answers[i] == dry_pattern(i, NEW, vocab), f"rank {rank}: clip {i} collated wrongly"
+    coll, _ = time_collective(parallel, toks, lens, n_global, rank, world, sync)
+    if rank == 0:
+        print(json.dumps({"metric": "videos/sec (DRY: no GPU work, control flow only)", "value": n_global * args.steps / elapsed, "unit": "videos/sec",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "dry",
+                          "config": {"workload": "dry run of the N-rank skeleton", "clips_per_gpu_per_step": B, "new_tokens": NEW, "parallelism": f"dp{world}"},
+                          "collective": coll, "clips_checked": n_global}), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_self(args))
+    if args.dry:
+        return main_dry(args)
     from video_llava_amd import _lib, parallel
     from video_llava_amd import random_init as ri
     from video_llava_amd.inference import get_spatio_temporal_features_torch
@@ -279,6 +374,9 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if os.environ.get("PGV_BENCH_SHARE_DEVICE"):        # control-flow smoke test of the N > 1 path on a 1-GPU box (with PGV_DIST_BACKEND=gloo)
         local = 0
+    elif torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} GPU(s) are visible (one rank per GPU; "
+                         "PGV_BENCH_SHARE_DEVICE=1 PGV_DIST_BACKEND=gloo runs the ranks on one device as a control-flow check)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
@@ -461,6 +559,14 @@ def main():
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.SUM)
         clip_feat_tflops_total = float(tt[0])
 
+    # ---- the one exchange step, timed alone (N > 1): all-gather of the answer buffer ---------------------------------
+    collective = None
+    if world > 1 and args.workload == "full":
+        toks_c = torch.stack([torch.tensor(dry_pattern(i, NEW, vocab), dtype=torch.int32) for i in mine]).to(dev)
+        lens_c = torch.full((B,), NEW, dtype=torch.int32, device=dev)
+        collective, ans_c = time_collective(parallel, toks_c, lens_c, n_global, rank, world, barrier)
+        assert all(ans_c[i] == dry_pattern(i, NEW, vocab) for i in range(n_global)), f"rank {rank}: collation mismatch"
+
     # ---- profiled pass: hipEvent pairs around every launch of each kernel family, on the launch stream -----------------
     fam = {}
     roofline = None
@@ -541,6 +647,8 @@ def main():
             "clip_feat_tflops_all_gpus": clip_feat_tflops_total,
             "clip_feat_ms_per_step": vit_ms,
         }
+        if collective:
+            line["collective"] = collective
         if pcie:
             line["pcie_inclusive"] = pcie
         if latency:

@@ -153,6 +153,35 @@ torch.distributed.destroy_process_group()
     assert ans == want
 
 
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_bench_launcher_dry_world2(launcher):
+    """`python bench.py --gpus 2` with no torchrun environment must start its own two ranks (the driver's command shape) and print
+    ONE rank-0 JSON line with n_gpus = 2 and the collective report; the torchrun form must keep working.  --dry: real sharding,
+    barriers, all-gather (gloo) and max-over-ranks timing, no GPU work."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry", "--steps", "3", "--warmup", "1", "--clips-per-gpu", "3", "--new-tokens", "5"]
+    if launcher == "self":
+        cmd = [sys.executable, *tail]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), *tail]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"
+    assert d["collective"]["backend"] == "gloo" and d["collective"]["world_seen"] == 2 and d["collective"]["gather_ms"] > 0
+    assert d["clips_checked"] == 6
+
+
+def test_bench_gpus_mismatch_is_loud():
+    """A WORLD_SIZE that contradicts --gpus is an error, not a silently different run."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
 def test_no_kernel_spills_to_scratch():
     """Every gfx950 kernel of libpgv must fit its registers: a spilled accumulator or DMA offset inside a GEMM/attention loop
     costs 2-3x (seen while building the 4-wave GEMM), so scratch use is a build failure, not a perf note."""

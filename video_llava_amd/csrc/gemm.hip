@@ -431,10 +431,12 @@ int launch_w4_inst(KArgs k, hipStream_t s, int num_cu) {
 
 template <typename T, int EPI>
 int launch_w4(const KArgs& k, hipStream_t s, int num_cu) {
+#ifdef PGV_LAB
     static int abl = -1;
     if (abl < 0) { const char* e = getenv("PGV_GEMM_ABLATE"); abl = e ? atoi(e) : 0; }
-    // Timing ablations (results are garbage), plain BIAS epilogue in bf16 only -- PGV_GEMM_ABLATE bits: 1 no DMA, 2 no fragment reads,
-    // 4 no MFMA, 8 no counted vmcnt wait, 16 no barrier, 32 no epilogue (scripts/microbench.py ablate; the table in DESIGN.md 3.1)
+    // Lab builds only (-DPGV_LAB): timing ablations (results are garbage), plain BIAS epilogue in bf16 only -- PGV_GEMM_ABLATE bits: 1 no DMA,
+    // 2 no fragment reads, 4 no MFMA, 8 no counted vmcnt wait, 16 no barrier, 32 no epilogue (scripts/microbench.py ablate).
+    // The release library has no switch that changes results.
     if constexpr (EPI == PGV_EPI_BIAS && T::id == PGV_BF16) {
         switch (abl) {
             case 1: return launch_w4_inst<T, EPI, 1>(k, s, num_cu);
@@ -446,6 +448,7 @@ int launch_w4(const KArgs& k, hipStream_t s, int num_cu) {
             default: break;
         }
     }
+#endif
     return launch_w4_inst<T, EPI, 0>(k, s, num_cu);
 }
 

@@ -33,9 +33,16 @@ struct AttnArgs {
     int N, C, heads;
     int nkb;           // ceil(N/32)
     float scale_log2e; // d^-0.5 * log2(e)
-    int abl;           // diagnostic ablation (PGV_ATTN_ABLATE): 1 = no V staging, 2 = no query loop, 4 = no K staging,
-                       // 8 = no exp (copy), 16 = no PV MFMAs, 32 = no S MFMAs, 64 = no max, 128 = static block assignment (wrong results for 8..64)
+#ifdef PGV_LAB
+    int abl;           // lab builds only (-DPGV_LAB, PGV_ATTN_ABLATE): 1 = no V staging, 2 = no query loop, 4 = no K staging,
+                       // 8 = no exp (copy), 16 = no PV MFMAs, 32 = no S MFMAs, 64 = no max (wrong results by design: timing ablations)
+#endif
 };
+#ifdef PGV_LAB
+#define PGV_ATTN_ABL(p) ((p).abl)
+#else
+#define PGV_ATTN_ABL(p) 0          // the release library has no switch that changes results
+#endif
 
 template <typename T, int ABL>
 __global__ __launch_bounds__(256) void vit_attn_kernel(AttnArgs p) {
@@ -83,12 +90,12 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(AttnArgs p) {
         for (int g = w; g < npad / 8; g += nw) {
             const int row = g * 8 + srow;
             const int rr = min(row, N - 1);
-            if (!(p.abl & 4)) {
+            if (!(PGV_ATTN_ABL(p) & 4)) {
                 const int chunk = slot ^ ((row >> 1) & 7);
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + ((row0 + rr) * p.ld + chunk * 8) * 2),
                                                  (__attribute__((address_space(3))) void*)(Ks + g * 1024), 16, 0, 0);
             }
-            if (!(p.abl & 1)) {
+            if (!(PGV_ATTN_ABL(p) & 1)) {
                 const int chunk = slot ^ (((row >> 1) & 1) << 2);
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + ((row0 + rr) * p.ld + chunk * 8) * 2),
                                                  (__attribute__((address_space(3))) void*)(Vs + g * 1024), 16, 0, 0);
@@ -204,7 +211,7 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(AttnArgs p) {
             }
     };
 
-    const int nblocks = (p.abl & 2) ? 0 : p.nkb;
+    const int nblocks = (PGV_ATTN_ABL(p) & 2) ? 0 : p.nkb;
     int qb = w, qb_next = next_block();
     for (; qb < nblocks; qb = qb_next, qb_next = next_block()) {
         typename T::v8 qf[4];
@@ -266,7 +273,9 @@ int pgv_launch_vit_attn(pgv_ctx* ctx, int dtype, const void* qkv, int ld, void* 
     a.nkb = (N + 31) / 32;
     const int npad = a.nkb * 32;
     a.scale_log2e = 0.125f * 1.4426950408889634f;
+#ifdef PGV_LAB
     { static int abl = -1; if (abl < 0) { const char* e = getenv("PGV_ATTN_ABLATE"); abl = e ? atoi(e) : 0; } a.abl = abl; }
+#endif
     const size_t lds = (size_t)npad * 256 + 16;    // K + V images + the query-block counter
     PGV_CHECK(lds <= 160 * 1024, "vit_attn: %d tokens per frame need %zu B of LDS (> 160 KiB)", N, lds);
     const int nw = 4;
@@ -278,6 +287,9 @@ int pgv_launch_vit_attn(pgv_ctx* ctx, int dtype, const void* qkv, int ld, void* 
     if (dtype == PGV_F16) {
         PGV_ATTN_LAUNCH(TF16, 0);
     } else if (dtype == PGV_BF16) {
+#ifndef PGV_LAB
+        PGV_ATTN_LAUNCH(TBF16, 0);
+#else
         switch (a.abl & 0x78) {                      // fine-grained ablations exist for bf16 only
             case 0: PGV_ATTN_LAUNCH(TBF16, 0); break;
             case 8: PGV_ATTN_LAUNCH(TBF16, 8); break;
@@ -289,6 +301,7 @@ int pgv_launch_vit_attn(pgv_ctx* ctx, int dtype, const void* qkv, int ld, void* 
             case 120: PGV_ATTN_LAUNCH(TBF16, 120); break;
             default: pgv_set_error("vit_attn: unsupported ablation %d", a.abl); return PGV_EINVAL;
         }
+#endif
     } else {
         pgv_set_error("vit_attn: unsupported dtype %d", dtype);
         return PGV_EINVAL;
