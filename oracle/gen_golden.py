@@ -37,10 +37,8 @@ from oracle import vision as ovis       # noqa: E402
 
 
 def _import_reference():
-    d = types.ModuleType("decord")
-    d.VideoReader = object
-    d.cpu = lambda i: None
-    sys.modules["decord"] = d
+    from oracle import decord_stub
+    decord_stub.install()                 # a decord whose VideoReader serves synthetic clips: the reference's load_video bodies execute
     sys.path.insert(0, REF)
     torch.Tensor.cuda = lambda self, *a, **k: self
 
@@ -87,6 +85,30 @@ def gen_seq_frames(meta):
     with open(os.path.join(OUT, "seq_frames.json"), "w") as f:
         json.dump(table, f)
     meta["seq_frames_cases"] = len(cases)
+
+
+LOAD_VIDEO_CASES = [("synth:137x20x26:3", (14, 14)),     # sampling 100 of 137 + down-sampling with odd ratios
+                    ("synth:7x14x14:4", (14, 14)),        # fewer frames than num_frm, already at the target size: no resize branch
+                    ("synth:300x10x12:5", (28, 28)),      # up-sampling
+                    ("synth:101x31x17:6", (14, 28))]      # non-square target (no aspect preservation)
+
+
+def gen_load_video(meta):
+    """The reference's two `load_video` bodies (eval/model_utils.py:12-52 and scripts/save_spatio_temporal_clip_features.py:13-32) executed
+    through the stub decord reader: frame sampling -> get_batch -> nearest resize -> PIL.  Stored: the frames as uint8 arrays."""
+    from video_chatgpt.eval.model_utils import load_video as ref_eval
+    spec = importlib.util.spec_from_file_location("ref_extract_lv", f"{REF}/scripts/save_spatio_temporal_clip_features.py")
+    ref_extract = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_extract)
+    out = {}
+    for i, (path, shape) in enumerate(LOAD_VIDEO_CASES):
+        a = np.stack([np.asarray(im) for im in ref_eval(path, shape=shape)])
+        b = np.stack([np.asarray(im) for im in ref_extract.load_video(path, shape=shape)])
+        assert a.dtype == np.uint8 and np.array_equal(a, b), path
+        out[f"case{i}"] = a
+    np.savez_compressed(os.path.join(OUT, "load_video.npz"), paths=np.array([c[0] for c in LOAD_VIDEO_CASES]),
+                        shapes=np.array([c[1] for c in LOAD_VIDEO_CASES]), **out)
+    meta["load_video_cases"] = len(LOAD_VIDEO_CASES)
 
 
 def gen_pool(meta):
@@ -382,6 +404,7 @@ def main():
             "reference_pinned_transformers": "git cae78c46 (requirements.txt:21)"}
     gen_frames_and_preprocess(meta)
     gen_seq_frames(meta)
+    gen_load_video(meta)
     gen_pool(meta)
     gen_clip_tiny(meta)
     gen_llama_tiny(meta)

@@ -115,6 +115,8 @@ def bench_decode(ctx, dtype=torch.bfloat16):
 
 if __name__ == "__main__":
     which = set(sys.argv[1:]) or {"gemm", "attn", "gemv"}
+    if "ablate" in which or os.environ.get("PGV_ATTN_ABLATE"):
+        _lib.use_lab_build()               # the ablation switches exist only in libpgv_lab.so (-DPGV_LAB)
     ctx = _lib.Context.get(0)
     if "gemm" in which:
         bench_gemm(ctx)

@@ -182,6 +182,18 @@ def test_bench_gpus_mismatch_is_loud():
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
 
 
+def test_release_library_has_no_lab_switches():
+    """Switches that produce garbage by design (timing ablations) must not exist in the library the product loads: they are compiled
+    only into libpgv_lab.so (-DPGV_LAB, video_llava_amd.build.build(lab=True)), which nothing under video_llava_amd/ binds."""
+    from video_llava_amd import build
+    lib = build.build()
+    blob = open(lib, "rb").read()
+    for needle in (b"PGV_GEMM_ABLATE", b"PGV_ATTN_ABLATE", b"ABLATE"):
+        assert needle not in blob, f"{needle!r} found in {lib}"
+    src = "".join(open(os.path.join(ROOT, "video_llava_amd", f)).read() for f in os.listdir(os.path.join(ROOT, "video_llava_amd")) if f.endswith(".py") and f != "_lib.py" and f != "build.py")
+    assert "use_lab_build" not in src and "libpgv_lab" not in src
+
+
 def test_no_kernel_spills_to_scratch():
     """Every gfx950 kernel of libpgv must fit its registers: a spilled accumulator or DMA offset inside a GEMM/attention loop
     costs 2-3x (seen while building the 4-wave GEMM), so scratch use is a build failure, not a perf note."""
@@ -462,3 +474,75 @@ def test_animated_gif_front_end(tmp_path):
     (tmp_path / "clip7").mkdir()
     assert _sharded.first_existing(str(tmp_path), "clip7", [".mp4", *_sharded.DECORD_FREE_FORMATS]) == str(tmp_path / "clip7")
     assert _sharded.first_existing(str(tmp_path), "absent", [".mp4", *_sharded.DECORD_FREE_FORMATS]) is None
+
+
+def test_load_video_decord_branches_match_reference(golden_dir, tmp_path):
+    """The decord branches of both `load_video` mirrors (reference video_chatgpt/eval/model_utils.py:12-52 and
+    scripts/save_spatio_temporal_clip_features.py:13-32) executed through a stub `decord.VideoReader` (decord is not installable offline):
+    frame sampling -> get_batch -> nearest resize -> PIL / uint8 array, byte-identical to what the REFERENCE's own functions returned
+    for the same stub clips (tests/golden/load_video.npz, written by oracle/gen_golden.py::gen_load_video)."""
+    from oracle import decord_stub
+    from video_llava_amd import feature_extraction as fx
+    from video_llava_amd.eval import model_utils as mu
+    g = np.load(os.path.join(golden_dir, "load_video.npz"))
+    decord_stub.install()
+    try:
+        for i, (path, shape) in enumerate(zip(g["paths"].tolist(), g["shapes"].tolist())):
+            want = g[f"case{i}"]
+            shape = tuple(int(x) for x in shape)
+            pil = mu.load_video(path, shape=shape)                           # eval/model_utils.py mirror: list of PIL images
+            assert len(pil) == want.shape[0] and all(im.size == (shape[1], shape[0]) and im.mode == "RGB" for im in pil)
+            assert np.array_equal(np.stack([np.asarray(im) for im in pil]), want), path
+            arr = fx.load_video(path, shape=shape)                           # extraction-script mirror: uint8 [k, h, w, 3]
+            assert arr.dtype == np.uint8 and np.array_equal(arr, want), path
+            nat = fx.load_video(path, shape=shape, device_resize=True)       # runner front end: native frames, resized on the device later
+            assert isinstance(nat, fx.NativeFrames) and np.array_equal(nat.resized(), want), path
+        # a real file path goes through the same branch (the stub reads .npy): the eval runners' route for v_<name>.mp4
+        clip = np.random.default_rng(9).integers(0, 256, (12, 9, 11, 3), dtype=np.uint8)
+        p = tmp_path / "v_x.npy"
+        np.save(p, clip)
+        os.rename(p, tmp_path / "v_x.mp4")
+        got = fx.sample_frames(str(tmp_path / "v_x.mp4"))
+        assert np.array_equal(got, clip[mu.get_seq_frames(12, 12)])          # note: not the identity -- the reference's midpoint rule repeats frames
+    finally:
+        decord_stub.uninstall()
+    with pytest.raises(RuntimeError, match="decord"):                        # without decord the error names what is missing
+        mu.load_video("synth:3x4x4:1")
+
+
+def test_run_sharded_prefetches_one_group_ahead():
+    """parallel.run_sharded with a `prepare` half: the host half of group g + 1 runs on a background thread while the device half of group g
+    runs; results and failure isolation are those of the serial loop (a prepare() exception fails only its own group)."""
+    import threading
+    import time
+    from video_llava_amd import parallel
+    events, lock = [], threading.Lock()
+
+    def log(*e):
+        with lock:
+            events.append(e)
+
+    def prepare(group):
+        log("prep_start", tuple(group), threading.current_thread().name)
+        time.sleep(0.05)
+        if 4 in group:
+            raise IOError("corrupt clip")
+        log("prep_end", tuple(group))
+        return {i: i * 10 for i in group}
+
+    def infer(group, prepared):
+        log("infer_start", tuple(group), threading.current_thread().name)
+        time.sleep(0.1)
+        toks = torch.tensor([[prepared[i], prepared[i] + 1, 0] for i in group], dtype=torch.int32)
+        log("infer_end", tuple(group))
+        return toks, [3 if i % 2 else 2 for i in group]           # length_offset 1: answers of 2 / 1 tokens
+
+    ans = parallel.run_sharded(7, infer, 3, 0, 1, torch.device("cpu"), per_gpu_batch=2, length_offset=1, prepare=prepare)
+    assert ans == [[0], [10, 11], [20], [30, 31], None, None, [60]]            # group (4, 5) failed in prepare; the rest is intact
+    names = [e[0:2] for e in events]
+    # overlap: the preparation of group 1 starts before the inference of group 0 ends, on another thread
+    assert names.index(("prep_start", (2, 3))) < names.index(("infer_end", (0, 1)))
+    main = threading.current_thread().name
+    assert all(e[2] != main for e in events if e[0] == "prep_start") and all(e[2] == main for e in events if e[0] == "infer_start")
+    # never more than one group ahead
+    assert names.index(("prep_start", (4, 5))) > names.index(("infer_start", (0, 1)))

@@ -88,6 +88,16 @@ _lib = None
 _lock = threading.Lock()
 
 
+def use_lab_build() -> None:
+    """Lab scripts only (scripts/microbench.py ablate): bind the -DPGV_LAB library, which carries the timing-ablation switches.  Must be called
+    before the first load(); nothing in the product calls it and no environment variable selects it."""
+    global LIB_PATH
+    if _lib is not None:
+        raise RuntimeError("libpgv is already loaded")
+    from . import build as _build
+    LIB_PATH = _build.build(lab=True)
+
+
 def load(build_if_missing: bool = True) -> C.CDLL:
     """Load libpgv.so (building it with hipcc first if it is not there).  Raises on any failure."""
     global _lib

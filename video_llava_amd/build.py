@@ -36,13 +36,38 @@ def _newest_header() -> float:
     return max(os.path.getmtime(h) for h in hs)
 
 
-def _compile(src: str, force: bool, verbose: bool) -> tuple[str, bool]:
+LAB_OBJ = os.path.join(HERE, "_build_lab")
+LAB_LIB = os.path.join(HERE, "libpgv_lab.so")     # -DPGV_LAB: timing-ablation switches compiled in (results are garbage under them); never loaded by the product
+
+
+def build_variant(name: str, defines: list[str], verbose: bool = False) -> str:
+    """Lab A/B builds: libpgv_<name>.so compiled with extra -D flags (objects under _build_<name>/).  Bound only by scripts/lab/with_lib.py."""
+    odir = os.path.join(HERE, f"_build_{name}")
+    os.makedirs(odir, exist_ok=True)
+    lib = os.path.join(HERE, f"libpgv_{name}.so")
+    objs = []
+    def one(src):
+        opath = os.path.join(odir, src.replace(".hip", ".o"))
+        cmd = [_hipcc(), *FLAGS, *[f"-D{d}" for d in defines], *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", opath]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
+        return opath
+    with concurrent.futures.ThreadPoolExecutor(max_workers=8) as ex:
+        objs = list(ex.map(one, sources_present()))
+    r = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stderr}")
+    return lib
+
+
+def _compile(src: str, force: bool, verbose: bool, lab: bool = False) -> tuple[str, bool]:
     spath = os.path.join(CSRC, src)
-    opath = os.path.join(OBJ, src.replace(".hip", ".o"))
+    opath = os.path.join(LAB_OBJ if lab else OBJ, src.replace(".hip", ".o"))
     stamp = max(os.path.getmtime(spath), _newest_header())
     if not force and os.path.exists(opath) and os.path.getmtime(opath) >= stamp:
         return opath, False
-    cmd = [_hipcc(), *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", spath, "-o", opath]
+    cmd = [_hipcc(), *FLAGS, *(["-DPGV_LAB"] if lab else []), *EXTRA_FLAGS.get(src, []), "-c", spath, "-o", opath]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -57,13 +82,15 @@ def sources_present() -> list[str]:
     return [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every HIP translation unit and link libpgv.so; returns the library path."""
-    os.makedirs(OBJ, exist_ok=True)
+def build(force: bool = False, verbose: bool = False, lab: bool = False) -> str:
+    """Compile every HIP translation unit and link libpgv.so; returns the library path.  lab=True builds the separate libpgv_lab.so with
+    -DPGV_LAB (the ablation switches of scripts/microbench.py); the release library contains none of them."""
+    os.makedirs(LAB_OBJ if lab else OBJ, exist_ok=True)
     srcs = sources_present()
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
-        results = list(ex.map(lambda s: _compile(s, force, verbose), srcs))
+        results = list(ex.map(lambda s: _compile(s, force, verbose, lab), srcs))
     objs = [o for o, _ in results]
+    LIB = LAB_LIB if lab else globals()["LIB"]
     if force or any(changed for _, changed in results) or not os.path.exists(LIB):
         cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
         if verbose:
@@ -75,4 +102,4 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, lab="--lab" in sys.argv))

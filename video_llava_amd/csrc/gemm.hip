@@ -33,6 +33,9 @@ struct KArgs {
     const float* gnext;     // producer: [N] gamma of the LayerNorm that follows
     char* x16; int ldx16;   // producer: 16-bit copy round16(resid * gnext), row stride ldx16 elements
     float* stats_part;      // producer: [N/64][M][2] partial (sum, sum of squares) of the new residual row over each 64-column piece
+#ifdef PGV_LAB
+    int stagger_ticks;      // lab: start delay unit (10 ns ticks), PGV_GEMM_STAGGER
+#endif
 };
 
 // Internal epilogues of the CLIP tower (not part of the public pgv_epi enum).  LayerNorm has no launch of its own:
@@ -154,21 +157,37 @@ __device__ __forceinline__ void epilogue_w4(const KArgs& p, f32x16_t (&acc)[4][4
             bv[jp] = *(const f32x4_t*)(p.bias + min(col, p.N - 4));
         }
     }
-    u32x2_t rst[8];                                            // LN_IN: (mean, rstd) of the 8 rows
+    // The epilogue's own loads are software-pipelined ONE STEP AHEAD (two register sets): the eight residual loads of piece p + 1 (RMW:
+    // a round trip to HBM) and the row statistics of row group i + 1 (LN_IN: L2) are issued before piece p is staged and finished, so a
+    // piece no longer starts with an exposed memory round trip.  (Issued-then-immediately-consumed they cost one round trip per piece:
+    // 8 x ~1.5 us of the ~22 us a 256 x 256 residual tile's epilogue took.)  Same arithmetic, same order: results are bit-identical.
+    u32x2_t rst[2][8];                                         // LN_IN: (mean, rstd) of the 8 rows, double-buffered over the row groups
+    u32x4_t old[2][8];                                         // RMW: the fp32 residual of a piece, double-buffered over the pieces
     float keep1 = 0.f, keep2 = 0.f;                            // LN_OUT: (sum, sum of squares) of the row this lane reports
+    auto load_rst = [&](int i, u32x2_t (&dst)[8]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) dst[r] = __builtin_amdgcn_raw_buffer_load_b64(rs_aux, (unsigned)(i * 32 + r * 4 + rrow) * 8u, 0, 0);
+    };
+    auto load_old = [&](int piece, u32x4_t (&dst)[8]) __attribute__((always_inline)) {
+        const int i = piece >> 1, jp = piece & 1;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) dst[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[jp] + (i * 32 + r * 4) * rowpitch, 0, 0);
+    };
+#ifdef PGV_LAB_EPI_NOPIPE
+    constexpr bool PIPE = false;                               // lab A/B build: loads issued right before their piece (the round-2 epilogue)
+#else
+    constexpr bool PIPE = true;
+#endif
+    if constexpr (LN_IN && PIPE) load_rst(0, rst[0]);
+    if constexpr (RMW && PIPE) load_old(0, old[0]);
 #pragma unroll
     for (int piece = 0; piece < 8; ++piece) {
         const int i = piece >> 1, jp = piece & 1;
         if constexpr (LN_IN) {
-            if (jp == 0) {
-#pragma unroll
-                for (int r = 0; r < 8; ++r) rst[r] = __builtin_amdgcn_raw_buffer_load_b64(rs_aux, (unsigned)(i * 32 + r * 4 + rrow) * 8u, 0, 0);
-            }
+            if (PIPE ? (jp == 0 && i < 3) : (jp == 0)) load_rst(PIPE ? i + 1 : i, rst[(PIPE ? i + 1 : i) & 1]);
         }
-        u32x4_t old[8];
         if constexpr (RMW) {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) old[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[jp] + (i * 32 + r * 4) * rowpitch, 0, 0);
+            if (PIPE ? (piece < 7) : true) load_old(PIPE ? piece + 1 : piece, old[(PIPE ? piece + 1 : piece) & 1]);
         }
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
@@ -190,7 +209,7 @@ __device__ __forceinline__ void epilogue_w4(const KArgs& p, f32x16_t (&acc)[4][4
                 __builtin_amdgcn_raw_buffer_store_b64(pack4<T>(silu_f(d[0]) * u[0], silu_f(d[1]) * u[1], silu_f(d[2]) * u[2], silu_f(d[3]) * u[3]), rsrc, o, 0, 0);
             } else {
                 if constexpr (LN_IN) {
-                    const f32x2_t ms = __builtin_bit_cast(f32x2_t, rst[r]);            // (mean, rstd)
+                    const f32x2_t ms = __builtin_bit_cast(f32x2_t, rst[i & 1][r]);            // (mean, rstd)
                     const float a = ms[1], c = -ms[1] * ms[0];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) d[e] = a * d[e] + (c * sv[jp][e] + bv[jp][e]);       // rstd (acc - mean s_n) + b'_n
@@ -207,7 +226,7 @@ __device__ __forceinline__ void epilogue_w4(const KArgs& p, f32x16_t (&acc)[4][4
                     }
                 }
                 if constexpr (RMW) {
-                    const f32x4_t q = __builtin_bit_cast(f32x4_t, old[r]);
+                    const f32x4_t q = __builtin_bit_cast(f32x4_t, old[piece & 1][r]);
                     d[0] += q[0]; d[1] += q[1]; d[2] += q[2]; d[3] += q[3];
                 }
                 if constexpr (OUT32) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, d), rsrc, o, 0, 0);
@@ -312,6 +331,12 @@ __global__ __launch_bounds__(256, 1) void gemm_w4(KArgs p) {
     using First = std::true_type;
     using Later = std::false_type;
     rebaseA(blockIdx.x); rebaseW(blockIdx.x);
+#ifdef PGV_LAB
+    if (p.stagger_ticks > 0) {      // lab: de-phase the workgroups of an XCD by a start delay of (slot % 4) * stagger_ticks of the 100 MHz clock
+        const unsigned long long t0 = wall_clock64(), wait = (unsigned long long)((blockIdx.x >> 3) & 3) * (unsigned long long)p.stagger_ticks;
+        while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
 
     const int l31 = lane & 31, hi = lane >> 5;
     const int sw = (l31 >> 1) & 7;
@@ -352,14 +377,17 @@ __global__ __launch_bounds__(256, 1) void gemm_w4(KArgs p) {
                 if (t < 4) fa[set ^ 1][t] = *(const typename T::v8*)(ra + a_off + t * 4096 + koffs[rkk]);
                 else fw[set ^ 1][t - 4] = *(const typename T::v8*)(rw + w_off + (t - 4) * 4096 + koffs[rkk]);
             }
-            if constexpr (dmasel >= 0) { if (t & 1) dma_one(Which{}, (dmasel & 1) * 4 + (t >> 1)); }
+            if constexpr (dmasel == 4) dma_one(S1{}, t);                         // the whole W tile in one group (one DMA per 2 MFMAs)
+            else if constexpr (dmasel >= 0) { if (t & 1) dma_one(Which{}, (dmasel & 1) * 4 + (t >> 1)); }
         }
-        if constexpr (dmasel >= 0 && (dmasel & 1)) advance(Which{});
+        if constexpr (dmasel == 4) advance(S1{});
+        else if constexpr (dmasel >= 0 && (dmasel & 1)) advance(Which{});
     };
     using DmaA0 = std::integral_constant<int, 0>;
     using DmaA1 = std::integral_constant<int, 1>;
     using DmaW0 = std::integral_constant<int, 2>;
     using DmaW1 = std::integral_constant<int, 3>;
+    using DmaWall = std::integral_constant<int, 4>;
 
     // prologue: A0 W0 A1 and the first half of W1 (slots 0 1 2 3); the loop continues with W1's second half
 #pragma unroll
@@ -371,9 +399,16 @@ __global__ __launch_bounds__(256, 1) void gemm_w4(KArgs p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) dma_one(S0{}, j);
     advance(S0{});
+#ifdef PGV_LAB_W_EARLY
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dma_one(S1{}, j);
+    advance(S1{});
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                  // K-step 0 landed (this wave's share)
+#else
 #pragma unroll
     for (int j = 0; j < 4; ++j) dma_one(S1{}, j);
     asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                  // K-step 0 landed (this wave's share)
+#endif
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int i = 0; i < 4; ++i) fa[0][i] = *(const typename T::v8*)(smem + a_off + i * 4096 + koffs[0]);
@@ -388,15 +423,22 @@ __global__ __launch_bounds__(256, 1) void gemm_w4(KArgs p) {
         const char* rw = smem + cw * SLOT;                                                                                  \
         int na = ca + 2; if (na >= 5) na -= 5;                                                                              \
         int nw = cw + 2; if (nw >= 5) nw -= 5;                                                                              \
-        group(FIRST{}, S0{}, ra, rw, 1, DmaW1{});                    /* + 2nd half of W(s+1) (slot of A(s-1))              */ \
+        group(FIRST{}, S0{}, ra, rw, 1, G0DMA{});                    /* + 2nd half of W(s+1) (slot of A(s-1))              */ \
         group(Later{}, S1{}, ra, rw, 2, DmaA0{});                    /* + A(s+2) into the slot W(s-1) left at the last barrier */ \
         group(Later{}, S0{}, ra, rw, 3, DmaA1{});                                                                           \
         if constexpr (ABL & 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                          \
         else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); /* step s+1 landed; only A(s+2) may still fly */   \
         if constexpr (!(ABL & 16)) __builtin_amdgcn_s_barrier();     /* ... for everyone, and step s is fully read */       \
-        group(Later{}, S1{}, smem + na * SLOT, smem + nw * SLOT, 0, DmaW0{}); /* + 1st half of W(s+2) into the slot of A(s) */ \
+        group(Later{}, S1{}, smem + na * SLOT, smem + nw * SLOT, 0, G3DMA{}); /* + 1st half of W(s+2) into the slot of A(s) */ \
         stg_slot = cw; ca = na; cw = nw;                                                                                    \
     }
+#ifdef PGV_LAB_W_EARLY
+    // lab variant: all of W(s+2) is issued in G3 of step s (right after the barrier that frees A(s)'s slot) instead of half there and half in
+    // G0 of step s+1: the tightest DMA deadline grows from 3 to 4 groups (is the K loop bound by the latency of that quarter of the bytes?)
+    using G0DMA = NoDma; using G3DMA = DmaWall;
+#else
+    using G0DMA = DmaW1; using G3DMA = DmaW0;
+#endif
     int stg_slot = 1;
     for (int vb = blockIdx.x; vb < total; vb += G) {
         PGV_W4_KSTEP(First)                                           // C = 0 form on the first k slice: no zeroing pass
@@ -442,6 +484,8 @@ int launch_w4(const KArgs& k, hipStream_t s, int num_cu) {
             case 1: return launch_w4_inst<T, EPI, 1>(k, s, num_cu);
             case 3: return launch_w4_inst<T, EPI, 3>(k, s, num_cu);
             case 6: return launch_w4_inst<T, EPI, 6>(k, s, num_cu);
+            case 8: return launch_w4_inst<T, EPI, 8>(k, s, num_cu);
+            case 12: return launch_w4_inst<T, EPI, 12>(k, s, num_cu);
             case 14: return launch_w4_inst<T, EPI, 14>(k, s, num_cu);
             case 24: return launch_w4_inst<T, EPI, 24>(k, s, num_cu);
             case 32: return launch_w4_inst<T, EPI, 32>(k, s, num_cu);
@@ -491,6 +535,9 @@ int pgv_launch_gemm(pgv_ctx* ctx, int dtype, const GemmArgs& a, hipStream_t s) {
     k.ntm = 0; k.ntn = 0;
     k.wblk = a.w_blocked ? 1 : 0;
     k.rowstat = a.rowstat; k.colsum = a.colsum; k.gnext = a.gnext; k.x16 = (char*)a.x16; k.ldx16 = a.ldx16; k.stats_part = a.stats_part;
+#ifdef PGV_LAB
+    { static int st = -1; if (st < 0) { const char* e = getenv("PGV_GEMM_STAGGER"); st = e ? atoi(e) : 0; } k.stagger_ticks = (a.epi == EPI_BIAS_RESID_LNOUT) ? st : 0; }
+#endif
     PGV_CHECK(!a.w_blocked || a.N % 16 == 0, "gemm: blocked weights need N %% 16 == 0");
     if (k.bias == nullptr) {        // the branch-free epilogue always reads a bias vector
         PGV_CHECK(a.N <= PGV_ZERO_BIAS_LEN, "gemm: N=%d exceeds the zero-bias vector", a.N);

@@ -4,8 +4,9 @@
 The reference's runners (video_chatgpt/eval/run_inference_*.py) all share one loop -- load the video, call
 `video_chatgpt_infer`, append the sample with its prediction, print and skip on any exception -- and differ only in how a
 sample names its video file and which keys the output record carries.  Here that loop is one function: tasks are sharded over
-the ranks (one process per GPU), each rank answers its shard in batches (one ViT pass per clip, batched prefill + KV-cached
-greedy decode in libpgv) and the only collective is the final all-gather of the answer token ids (video_llava_amd/parallel.py).
+the ranks (one process per GPU), each rank answers its shard in groups of `--batch` clips: ONE ViT pass over all frames of the group
+(the launch shape bench.py measures), batched prefill + KV-cached greedy decode in libpgv, while a background thread decodes the next
+group's frames into pinned memory; the only collective is the final all-gather of the answer token ids (video_llava_amd/parallel.py).
 A task whose video is missing or fails yields None (the reference prints and leaves the sample out).
 `do_sample=True` restores the reference's temperature-0.2 sampling through `video_chatgpt_infer`, one task at a time.
 """
@@ -43,29 +44,58 @@ def setup(args, components=None):
 def answer_tasks(args, tasks, components, load_frames, rank, world):
     """tasks: [{"path": str | None, "name": str, "question": str}] -> [str | None] in task order, identical on every rank."""
     from .. import parallel
-    from ..inference import build_prompt, video_chatgpt_infer, video_features
+    from ..inference import build_prompt, video_chatgpt_infer, video_features, video_features_batch
 
     model, vision_tower, tokenizer, image_processor, video_token_len = components
     use_se = model.get_model().vision_config.use_vid_start_end
     stop_strs = {}
 
-    def infer_batch(indices):
+    def prepare(indices):
+        """HOST half of a group, run one group ahead on the prefetch thread (parallel.run_sharded): decode / sample the frames of the group's
+        distinct clips into pinned memory.  -> {path: frames | Exception}"""
+        from ..feature_extraction import pin_frames
+        clips = {}
+        for idx in indices:
+            path = tasks[idx]["path"]
+            if path is None or path in clips:
+                continue
+            try:
+                clips[path] = pin_frames(load_frames(path))
+            except Exception as e:                                     # noqa: BLE001 -- reported per task below, like the reference's except
+                clips[path] = e
+        return clips
+
+    def infer_batch(indices, clips=None):
         """-> (tokens [n, <= max_new] int32, lengths).  Length encoding: 0 = the task failed (no prediction), k + 1 = an answer of k tokens
-        (k = 0 is a legitimate empty answer: the reference writes pred = '' when the first token is EOS)."""
+        (k = 0 is a legitimate empty answer: the reference writes pred = '' when the first token is EOS).
+        DEVICE half of a group: ONE tower pass over the frames of all distinct clips of the group (inference.video_features_batch; bitwise
+        equal to per-clip passes), then batched prefill + decode."""
+        if clips is None:
+            clips = prepare(indices)
+        good = [p for p, f in clips.items() if not isinstance(f, Exception)]
+        feat_of = {}
+        if good:
+            try:
+                feat_of = dict(zip(good, video_features_batch([clips[p] for p in good], vision_tower, image_processor)))
+            except Exception as e:                                     # noqa: BLE001 -- one bad clip must not take the group down
+                print(f"batched feature extraction failed ({e}); retrying the {len(good)} clips one by one")
+                for p in good:
+                    try:
+                        feat_of[p] = video_features(clips[p], vision_tower, image_processor)
+                    except Exception as e1:                            # noqa: BLE001
+                        clips[p] = e1
         prompts, feats, keep = [], [], []
-        last_path, last_feat = None, None
         for j, idx in enumerate(indices):
             t = tasks[idx]
             if t["path"] is None:
                 print(f"Error processing video file '{t['name']}': not found")
                 continue
             try:
-                if t["path"] != last_path:                             # consecutive questions on one clip share its features
-                    last_feat = video_features(load_frames(t["path"]), vision_tower, image_processor)
-                    last_path = t["path"]
+                if t["path"] not in feat_of:
+                    raise clips[t["path"]]
                 prompt, stop = build_prompt(t["question"], args.conv_mode, video_token_len, use_se)
                 ids = tokenizer([prompt]).input_ids[0]
-                feats.append(last_feat)
+                feats.append(feat_of[t["path"]])
                 stop_strs[idx] = stop
                 prompts.append(ids)
                 keep.append(j)
@@ -120,7 +150,7 @@ def answer_tasks(args, tasks, components, load_frames, rank, world):
 
     device = vision_tower.device if hasattr(vision_tower, "device") else torch.device("cpu")
     answers = parallel.run_sharded(len(tasks), infer_batch, args.max_new_tokens, rank, world, device, per_gpu_batch=args.batch,
-                                   length_offset=1)
+                                   length_offset=1, prepare=prepare)
     from ..model.utils import first_stop_length
     preds = []
     for idx, ids in enumerate(answers):

@@ -45,6 +45,20 @@ class NativeFrames:
         return resize_nearest(self.array, self.shape)
 
 
+def pin_frames(frames):
+    """Move sampled frames (NativeFrames or a uint8 array) into page-locked host memory so the upload is one asynchronous DMA (called on the
+    runners' prefetch thread).  Without a GPU runtime the frames are returned unchanged."""
+    if not torch.cuda.is_available():
+        return frames
+    arr = frames.array if isinstance(frames, NativeFrames) else frames
+    if not (isinstance(arr, np.ndarray) and arr.dtype == np.uint8):
+        return frames
+    pinned = torch.empty(arr.shape, dtype=torch.uint8).pin_memory()
+    view = pinned.numpy()
+    view[...] = arr
+    return NativeFrames(view, frames.shape) if isinstance(frames, NativeFrames) else view
+
+
 def resize_nearest(arr: np.ndarray, shape) -> np.ndarray:
     h, w = shape
     if arr.shape[-3] == h and arr.shape[-2] == w:

@@ -76,6 +76,43 @@ def video_features(video_frames, vision_tower, image_processor) -> torch.Tensor:
     return get_spatio_temporal_features_torch(frame_features)
 
 
+def video_features_batch(clips, vision_tower, image_processor):
+    """Several clips (ragged frame counts) -> list of [100 + P, 1024] fp16 pooled features with ONE tower pass over the concatenated frames.
+    The tower is bitwise batch-split invariant (tests/test_gpu_vision.py::test_vit_100_frames_properties), so every entry equals
+    `video_features(clip)` bit for bit; what changes is the launch shape: 8 clips x 100 frames fill the persistent GEMM's 256 CUs with
+    3216 + tiles per launch instead of 404, and there is one launch sequence instead of eight.  Clips that share a native resolution are
+    uploaded and ingested (nearest resize + CLIP normalisation, pgv_ingest_u8) together."""
+    from .feature_extraction import NativeFrames
+    S = vision_tower.config.image_size
+    dev = vision_tower.device
+    px_parts, counts = [], []
+    i = 0
+    while i < len(clips):
+        c = clips[i]
+        j = i + 1
+        if isinstance(c, NativeFrames) and c.shape == (S, S):
+            # run of clips decoded at the same native resolution: one upload, one ingest launch
+            while j < len(clips) and isinstance(clips[j], NativeFrames) and clips[j].shape == (S, S) and clips[j].array.shape[1:] == c.array.shape[1:]:
+                j += 1
+            host = [torch.as_tensor(x.array) for x in clips[i:j]]
+            up = torch.cat([h.to(dev, non_blocking=True) for h in host]) if len(host) > 1 else host[0].to(dev, non_blocking=True)
+            px_parts.append(_lib.Context.get(dev).ingest_u8(up.contiguous(), S, vision_tower.dtype))
+            counts.extend(int(h.shape[0]) for h in host)
+        else:
+            px = frames_to_pixels(c, image_processor, vision_tower)
+            px_parts.append(px)
+            counts.append(int(px.shape[0]))
+        i = j
+    px = torch.cat(px_parts) if len(px_parts) > 1 else px_parts[0]
+    with torch.no_grad():
+        hid = vision_tower(px, output_hidden_states=True).hidden_states[-2]
+    out, off = [], 0
+    for t in counts:
+        out.append(get_spatio_temporal_features_torch(hid[off:off + t, 1:]))
+        off += t
+    return out
+
+
 def video_chatgpt_infer(video_frames, question, conv_mode, model, vision_tower, tokenizer, image_processor, video_token_len,
                         transcript=None, do_sample=True, temperature=0.2, max_new_tokens=1024):
     """Answer `question` about one clip.  Same positional signature and defaults as the reference

@@ -72,24 +72,41 @@ def gather_answers(tokens: torch.Tensor, lengths: torch.Tensor, n_items: int, ra
     return answers
 
 
-def run_sharded(n_items: int, infer_batch: Callable[[Sequence[int]], tuple], max_new_tokens: int, rank: int, world: int,
-                device, per_gpu_batch: int = 8, length_offset: int = 0):
+def run_sharded(n_items: int, infer_batch: Callable[..., tuple], max_new_tokens: int, rank: int, world: int,
+                device, per_gpu_batch: int = 8, length_offset: int = 0, prepare: Callable[[Sequence[int]], object] | None = None):
     """Run `infer_batch(indices) -> (tokens [len(indices), <=max_new] int tensor, lengths list)` over this rank's shard in
     groups of `per_gpu_batch`, then collate.  A group that raises keeps its slots with length 0.  `length_offset`: see gather_answers
-    (the token count stored for slot j is lengths[j] - length_offset)."""
+    (the token count stored for slot j is lengths[j] - length_offset).
+    `prepare(indices) -> obj` (optional) is the HOST half of a group (decode / sample the frames, pin them): it runs on a background thread
+    ONE GROUP AHEAD of the device half, which then receives its result as `infer_batch(indices, obj)` -- the GPU works on group g while the
+    host reads group g + 1.  An exception inside `prepare` is delivered to the group it belongs to (that group fails, the others go on)."""
     mine = shard_indices(n_items, rank, world)
     cap = shard_capacity(n_items, world)
     tokens = torch.zeros(cap, max_new_tokens, dtype=torch.int32, device=device)
     lengths = torch.full((cap,), -1, dtype=torch.int32, device=device)
-    for g0 in range(0, len(mine), per_gpu_batch):
-        group = mine[g0:g0 + per_gpu_batch]
-        try:
-            toks, lens = infer_batch(group)
-            for j in range(len(group)):
-                n = max(int(lens[j]) - length_offset, 0)
-                tokens[g0 + j, :n] = toks[j, :n].to(device=device, dtype=torch.int32)
-                lengths[g0 + j] = int(lens[j])
-        except Exception as e:                               # noqa: BLE001 -- same "print and continue" policy as the reference
-            print(f"[rank {rank}] Error processing clips {group}: {e}")
-            lengths[g0:g0 + len(group)] = 0
+    groups = [mine[g0:g0 + per_gpu_batch] for g0 in range(0, len(mine), per_gpu_batch)]
+    pool = fut = None
+    if prepare is not None and groups:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="pgv-prefetch")
+        fut = pool.submit(prepare, groups[0])
+    try:
+        for gi, group in enumerate(groups):
+            g0 = gi * per_gpu_batch
+            try:
+                if pool is not None:
+                    prepared_f, fut = fut, (pool.submit(prepare, groups[gi + 1]) if gi + 1 < len(groups) else None)
+                    toks, lens = infer_batch(group, prepared_f.result())
+                else:
+                    toks, lens = infer_batch(group)
+                for j in range(len(group)):
+                    n = max(int(lens[j]) - length_offset, 0)
+                    tokens[g0 + j, :n] = toks[j, :n].to(device=device, dtype=torch.int32)
+                    lengths[g0 + j] = int(lens[j])
+            except Exception as e:                               # noqa: BLE001 -- same "print and continue" policy as the reference
+                print(f"[rank {rank}] Error processing clips {group}: {e}")
+                lengths[g0:g0 + len(group)] = 0
+    finally:
+        if pool is not None:
+            pool.shutdown(wait=True, cancel_futures=True)
     return gather_answers(tokens, lengths, n_items, rank, world, length_offset)
