@@ -111,10 +111,30 @@ def pmc_traffic(family):
             "traffic_source": os.path.relpath(files[-1], ROOT)}
 
 
+def _interleave_host_memory():
+    """numactl --interleave=all for this process, without numactl: set_mempolicy(MPOL_INTERLEAVE) over every NUMA node of the box, so the
+    27 GB of fp32 weights of the CPU baseline are spread over all memory controllers whichever thread first touches them (a model filled by
+    one thread otherwise lands on one socket's DIMMs and the decode GEMVs, which only stream weights, run at a fraction of the box's
+    bandwidth -- the round-2 baseline measured 35 GB/s on a 256-thread host).  Returns the number of nodes, 0 if the call is refused."""
+    import ctypes
+    import glob
+    nodes = sorted(int(p.rsplit("node", 1)[1]) for p in glob.glob("/sys/devices/system/node/node[0-9]*"))
+    if len(nodes) < 2:
+        return len(nodes)
+    mask = 0
+    for n in nodes:
+        mask |= 1 << n
+    words = (ctypes.c_ulong * ((max(nodes) // 64) + 1))(*[(mask >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(max(nodes) // 64 + 1)])
+    MPOL_INTERLEAVE, SYS_set_mempolicy = 3, 238                     # x86_64
+    rc = ctypes.CDLL(None, use_errno=True).syscall(SYS_set_mempolicy, MPOL_INTERLEAVE, words, max(nodes) + 2)
+    return len(nodes) if rc == 0 else 0
+
+
 def _fast_hf_build(cls, cfg):
     """Instantiate an HF model without its per-module random initialisation (the reference's own `disable_torch_init`,
     video_chatgpt/utils.py, does the same before from_pretrained), then fill the matrices from a tiled random block: values do not change
-    CPU matmul time, an N(0, 0.02) block keeps every intermediate finite."""
+    CPU matmul time, an N(0, 0.02) block keeps every intermediate finite.  The fill is one broadcast copy per tensor, which ATen runs on
+    the whole thread pool: pages are first touched by many threads (and interleaved over the NUMA nodes, _interleave_host_memory)."""
     import transformers.modeling_utils as mu
     saved = (torch.nn.Linear.reset_parameters, torch.nn.Embedding.reset_parameters, torch.nn.LayerNorm.reset_parameters, mu.PreTrainedModel.init_weights)
     torch.nn.Linear.reset_parameters = lambda self: None
@@ -125,16 +145,18 @@ def _fast_hf_build(cls, cfg):
         m = cls(cfg)
     finally:
         torch.nn.Linear.reset_parameters, torch.nn.Embedding.reset_parameters, torch.nn.LayerNorm.reset_parameters, mu.PreTrainedModel.init_weights = saved
-    block = torch.randn(1 << 20, generator=torch.Generator().manual_seed(0)) * 0.02
+    block = torch.randn(1 << 16, generator=torch.Generator().manual_seed(0)) * 0.02
     with torch.no_grad():
         for _n, p in m.named_parameters():
             if p.dim() == 1:
                 p.fill_(1.0 if p.numel() in (cfg.hidden_size,) and "bias" not in _n else 0.0)
             else:
                 flat = p.view(-1)
-                for o in range(0, flat.numel(), block.numel()):
-                    k = min(block.numel(), flat.numel() - o)
-                    flat[o:o + k].copy_(block[:k])
+                full = flat.numel() // block.numel() * block.numel()
+                if full:
+                    flat[:full].view(-1, block.numel()).copy_(block.expand(full // block.numel(), -1))
+                if full < flat.numel():
+                    flat[full:].copy_(block[:flat.numel() - full])
     return m.eval()
 
 
@@ -147,17 +169,17 @@ def cpu_baseline_reference(args):
     pooling is the oracle's verbatim restatement of the reference's numpy function.
       (i)  BASELINE config 1 in full: 8 frames, fp32, eager attention, all 24 CLIP layers (what the reference executes) -> hidden_states[-2][:, 1:]
            -> numpy pooling -> [356, 1024] fp16.
-      (ii) decoder: LLaMA-7B/13B-shaped LlamaForCausalLM.forward, fp32, eager attention, lm_head on all positions as the reference computes it
-           (model/video_chatgpt.py:226): prefill of the ~450-token prompt and 8 KV-cached decode steps at 8 and at 4 layers; the per-layer
-           and fixed parts are separated by the difference and extended to the full depth (layers are identical, the extension is exact up
-           to timing noise).  Thread counts {torch default, 64, 32, 16, 8} are tried for the decode step (small GEMVs do not scale to 128 threads),
-           the best is kept per stage."""
+      (ii) decoder at FULL DEPTH (32 / 40 layers, fp32 weights: 27 / 52 GB, NUMA-interleaved): LlamaForCausalLM.forward, eager attention, lm_head
+           on all positions as the reference computes it (model/video_chatgpt.py:226): one prefill of the ~450-token prompt and KV-cached decode
+           steps, timed directly (no per-layer differencing).  Thread counts are tried per stage (small GEMVs do not scale to every core), the
+           best is kept; the decode step is also reported per layer and as GB/s of fp32 weights streamed."""
     import transformers
     from transformers import CLIPVisionConfig, CLIPVisionModel, LlamaConfig, LlamaForCausalLM
     from oracle import synth
     from oracle import vision as ovis
     t_all = time.perf_counter()
     ncores = os.cpu_count() or 1
+    numa_nodes = _interleave_host_memory()
     default_threads = torch.get_num_threads()
     frames = synth.make_frames(8, 224, seed=0)
     ccfg = CLIPVisionConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16, image_size=224, patch_size=14,
@@ -166,7 +188,7 @@ def cpu_baseline_reference(args):
     px = ovis.clip_preprocess(frames)
     vit_times = {}
     with torch.no_grad():
-        for th in sorted({default_threads, min(32, ncores), min(16, ncores), min(8, ncores)}, reverse=True):
+        for th in sorted({default_threads, min(32, ncores), min(16, ncores)}, reverse=True):
             torch.set_num_threads(th)
             clip(px[:1], output_hidden_states=True)                                   # warm-up
             best = 1e9
@@ -179,40 +201,45 @@ def cpu_baseline_reference(args):
     t_cfg1 = min(vit_times.values())
     del clip
     full_layers, H, I, heads = (32, 4096, 11008, 32) if args.llm == "7b" else (40, 5120, 13824, 40)
-    L_hi, L_lo, n_step = 8, 4, 8
-    lcfg = LlamaConfig(vocab_size=32003, hidden_size=H, intermediate_size=I, num_hidden_layers=L_hi, num_attention_heads=heads, num_key_value_heads=heads,
+    torch.set_num_threads(default_threads)
+    t_build = time.perf_counter()
+    lcfg = LlamaConfig(vocab_size=32003, hidden_size=H, intermediate_size=I, num_hidden_layers=full_layers, num_attention_heads=heads, num_key_value_heads=heads,
                        max_position_embeddings=4096, rms_norm_eps=1e-5, attn_implementation="eager")
     llm = _fast_hf_build(LlamaForCausalLM, lcfg)
+    t_build = time.perf_counter() - t_build
+    weight_bytes = sum(p.numel() for n, p in llm.named_parameters() if "embed_tokens" not in n) * 4.0
     ids = torch.tensor([make_prompts(1, 32003, 356, 0)[0]])
     S = ids.shape[1]
+    n_step = 3
 
-    def run(threads):
+    def prefill(threads):
         torch.set_num_threads(threads)
         with torch.no_grad():
             t0 = time.perf_counter()
             o = llm(input_ids=ids, use_cache=True)
-            t_pre = time.perf_counter() - t0
+            return time.perf_counter() - t0, o
+
+    def decode(threads, o):
+        torch.set_num_threads(threads)
+        with torch.no_grad():
             tok = o.logits[:, -1].argmax(-1, keepdim=True)
             o = llm(input_ids=tok, past_key_values=o.past_key_values, use_cache=True)   # first step warms the decode shapes
             t0 = time.perf_counter()
             for _ in range(n_step):
                 tok = o.logits[:, -1].argmax(-1, keepdim=True)
                 o = llm(input_ids=tok, past_key_values=o.past_key_values, use_cache=True)
-            return t_pre, (time.perf_counter() - t0) / n_step
+            return (time.perf_counter() - t0) / n_step, o
 
-    cand = sorted({default_threads, min(64, ncores), min(32, ncores), min(16, ncores), min(8, ncores)}, reverse=True)
-    hi = {th: run(th) for th in cand}
-    th_pre = min(hi, key=lambda t: hi[t][0])
-    th_step = min(hi, key=lambda t: hi[t][1])
-    all_layers = llm.model.layers
-    llm.model.layers = all_layers[:L_lo]
-    lo_pre, _ = run(th_pre)
-    _, lo_step = run(th_step)
-    llm.model.layers = all_layers
-    pre_hi, step_hi = hi[th_pre][0], hi[th_step][1]
-    pre_layer, step_layer = (pre_hi - lo_pre) / (L_hi - L_lo), (step_hi - lo_step) / (L_hi - L_lo)
-    pre_full = pre_hi + (full_layers - L_hi) * pre_layer
-    step_full = step_hi + (full_layers - L_hi) * step_layer
+    cand = sorted({default_threads, min(64, ncores), min(32, ncores), min(16, ncores)}, reverse=True)
+    pre, o = {}, None
+    for th in cand[:2]:                                   # the prefill is GEMM-shaped: the two largest thread counts
+        pre[th], o = prefill(th)
+    step = {}
+    for th in cand:
+        step[th], o = decode(th, o)
+    th_pre, th_step = min(pre, key=pre.get), min(step, key=step.get)
+    pre_full, step_full = pre[th_pre], step[th_step]
+    del llm, o
     torch.set_num_threads(default_threads)
     clip_s = t_cfg1 * (args.frames / 8.0) + pre_full + step_full * (args.new_tokens - 1)
     return {"value": 1.0 / clip_s, "unit": "videos/sec", "cores": ncores, "kind": "reference",
@@ -220,14 +247,17 @@ def cpu_baseline_reference(args):
                           "reference's path executes (it has no arithmetic of its own beyond the numpy pooling, restated verbatim); the reference's glue "
                           "files cannot travel to the GPU box"),
             "threads_tried": cand, "threads_used": {"vit": min(vit_times, key=vit_times.get), "prefill": th_pre, "decode_step": th_step},
+            "numa_nodes_interleaved": numa_nodes, "layers_timed": full_layers, "model_build_s": t_build,
             "config1_8_frames_s": t_cfg1, "config1_by_threads_s": vit_times,
-            "prefill_s_at_8_layers": pre_hi, "decode_step_s_at_8_layers": step_hi, "prefill_s_per_layer": pre_layer, "decode_step_s_per_layer": step_layer,
-            "prefill_s_full_depth": pre_full, "decode_step_s_full_depth": step_full, "by_threads_at_8_layers": {str(k): v for k, v in hi.items()},
+            "prefill_s_full_depth": pre_full, "decode_step_s_full_depth": step_full, "prefill_by_threads_s": {str(k): v for k, v in pre.items()},
+            "decode_step_by_threads_s": {str(k): v for k, v in step.items()},
+            "decode_step_s_per_layer": step_full / full_layers, "decode_weight_stream_gbs": weight_bytes / step_full / 1e9,
+            "survey_probe_decode_step_s_per_layer": 0.0094 if args.llm == "7b" else 0.0146,     # BASELINE.md 3 (8-core build container)
             "sample": (f"BASELINE config 1 in full (8 frames, 24-layer ViT-L/14 fp32 eager + numpy pool: {t_cfg1:.2f}s) scaled to {args.frames} frames; "
-                       f"{args.llm.upper()}-shaped LlamaForCausalLM fp32 eager at {L_hi} and {L_lo} layers: prefill S={S} ({pre_hi:.2f}s at {L_hi} layers) + "
-                       f"{n_step} decode steps ({step_hi * 1e3:.0f} ms each at {L_hi} layers), per-layer cost by difference, extended to {full_layers} layers "
-                       f"= prefill {pre_full:.1f}s + {args.new_tokens - 1} x {step_full * 1e3:.0f} ms -> {clip_s:.1f}s/clip; sample took "
-                       f"{time.perf_counter() - t_all:.0f}s"),
+                       f"{args.llm.upper()}-shaped LlamaForCausalLM fp32 eager at FULL depth ({full_layers} layers, {weight_bytes / 1e9:.1f} GB of weights, "
+                       f"interleaved over {numa_nodes} NUMA nodes): prefill S={S} {pre_full:.2f}s + {n_step} timed decode steps of {step_full * 1e3:.0f} ms "
+                       f"({step_full / full_layers * 1e3:.1f} ms per layer, {weight_bytes / step_full / 1e9:.0f} GB/s) -> prefill + {args.new_tokens - 1} steps "
+                       f"= {clip_s:.1f}s/clip; sample took {time.perf_counter() - t_all:.0f}s"),
             "seconds_per_clip": clip_s}
 
 

@@ -27,9 +27,25 @@ from oracle import llm as ollm
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
-TOL_7B_FP16 = 8.1e-3      # normwise logits error: 1.2 x the 6.72e-3 measured on MI355X (2 layers: 1.84e-3; sixteen-fold depth -> x sqrt(16) = 4:
-                          # independent 16-bit roundings of xn / qkv / P / attention out / SwiGLU act per layer; the residual stream itself is fp32)
-TOL_13B_FP8_FP16 = 1.33e-2  # 1.2 x the worst decode-step error measured on MI355X (1.105e-2; prefill 6.98e-3)
+# Tolerances.  The YARDSTICK is the reference itself: tests/golden/yardstick.npz (oracle/gen_yardstick.py) holds the last-position logits of
+# the reference's own VideoChatGPTLlamaForCausalLM run in 16 bits on the host for the same full-depth case, and its normwise error against
+# the fp32 oracle.  The HIP path must stay within YARD_FACTOR x the reference's own distance from exact arithmetic.  The REGRESSION pins
+# (1.2 x what this path measured on MI355X) stay as a second, tighter bar so that a lost digit cannot hide under the yardstick.
+YARD_FACTOR = 1.25
+TOL_7B_FP16 = 8.1e-3        # regression pin: 1.2 x 6.72e-3 (2 layers: 1.84e-3; x sqrt(16): independent 16-bit roundings per layer, fp32 residual)
+TOL_13B_FP8_FP16 = 1.33e-2  # regression pin: 1.2 x the worst decode step measured (1.105e-2; prefill 6.98e-3)
+
+
+def _yard(golden_dir, case, truth_logits):
+    """(the reference's own 16-bit error, recomputed against THIS run's oracle logits; must reproduce the stored figure)."""
+    import os
+    y = np.load(os.path.join(golden_dir, "yardstick.npz"))
+    ref = torch.from_numpy(y[f"{case}_ref_logits"])
+    assert torch.allclose(torch.as_tensor(truth_logits).float().cpu()[::97], torch.from_numpy(y[f"{case}_truth_sub"]), rtol=1e-3, atol=2e-3), \
+        "the fixture does not belong to this case (oracle logits differ)"
+    e = rel(ref, truth_logits)
+    assert abs(e - float(y[f"{case}_ref_err"])) < 0.05 * e + 1e-4, (e, float(y[f"{case}_ref_err"]))
+    return e
 
 
 def rel(a, b) -> float:
@@ -61,7 +77,7 @@ def _build(name, dtype):
     return c, cfg, w, m
 
 
-def test_7b_full_depth_fp16_token_exact(ctx):
+def test_7b_full_depth_fp16_token_exact(ctx, golden_dir):
     c, cfg, w, m = _build("7b", torch.float16)
     ids, feats = fd.make_prompt(cfg, c["prompt_seed"])
     t0 = time.time()
@@ -70,8 +86,10 @@ def test_7b_full_depth_fp16_token_exact(ctx):
     assert min(margins) > c["floor"], f"oracle margin {min(margins)} below the floor {c['floor']}: pick another seed (oracle/fulldepth.py)"
     kv, nxt, lg = m.prefill([ids], feats.half(), 512, want_logits=True)
     e = rel(lg[0], logits_ref[0])
-    print(f"[7b] 32-layer prefill logits rel err (fp16): {e:.3e}")
-    assert e < TOL_7B_FP16
+    e_ref = _yard(golden_dir, "7b_fp16", logits_ref[0])
+    print(f"[7b] 32-layer prefill logits rel err (fp16): {e:.3e}; the reference's own fp16 run: {e_ref:.3e}")
+    assert e < YARD_FACTOR * e_ref, (e, e_ref)          # the yardstick: no further from exact arithmetic than the reference itself (x 1.25)
+    assert e < TOL_7B_FP16                              # regression pin
     toks = [int(nxt[0])] + m.decode_greedy(kv, nxt, fd.N_NEW - 1)[0].tolist()
     assert toks == toks_ref, (toks, toks_ref, margins)
     # the same prompt through generate(): prompt echoed, same tokens
@@ -87,7 +105,7 @@ def test_7b_full_depth_fp16_token_exact(ctx):
     assert worst < TOL_7B_FP16
 
 
-def test_13b_full_depth_fp8_weights_fp16_token_exact(ctx):
+def test_13b_full_depth_fp8_weights_fp16_token_exact(ctx, golden_dir):
     """BASELINE config 5 at full depth: 13B shapes, 40 layers, e4m3 weights (per-row power-of-two scales), fp16 activations (the reference's
     dtype); oracle = fp32 on the dequantised weights the library reports.  Free-running, token-exact, margin floor asserted."""
     c, cfg, w, m = _build("13b", torch.float16)
@@ -113,7 +131,9 @@ def test_13b_full_depth_fp8_weights_fp16_token_exact(ctx):
     assert min(margins) > c["floor"], f"oracle margin {min(margins)} below the floor {c['floor']}: pick another seed (oracle/fulldepth.py)"
     kv, nxt, lg = m.prefill([ids], feats.half(), 512, want_logits=True)
     e = rel(lg[0], logits_ref[0])
-    print(f"[13b fp8] 40-layer prefill logits rel err (fp16): {e:.3e}")
+    e_ref = _yard(golden_dir, "13b_fp8_fp16", logits_ref[0])
+    print(f"[13b fp8] 40-layer prefill logits rel err (fp16): {e:.3e}; the reference's own fp16 run on the same dequantised weights: {e_ref:.3e}")
+    assert e < YARD_FACTOR * e_ref, (e, e_ref)
     assert e < TOL_13B_FP8_FP16
     toks = [int(nxt[0])] + m.decode_greedy(kv, nxt, fd.N_NEW - 1)[0].tolist()
     assert toks == toks_ref, (toks, toks_ref, margins)
@@ -124,3 +144,61 @@ def test_13b_full_depth_fp8_weights_fp16_token_exact(ctx):
         worst = max(worst, rel(lg[0], logits_ref[i]))
     print(f"[13b fp8] worst decode-step logits rel err: {worst:.3e}")
     assert worst < TOL_13B_FP8_FP16
+
+
+def _teacher_forced_check(tag, m, cfg, w, ids, feats, cont, dtype, golden_dir, yard_case, n_min=12, sigmas=6.0):
+    """Teacher-force `cont` through the HIP model and compare every visited position with the fp32 oracle's logits (one causal pass):
+    logits error bounded by the yardstick, and at every position whose oracle top-1/top-2 margin exceeds `sigmas` x the MEASURED per-logit
+    noise of this run (std over the vocabulary of hip - oracle at that position) the argmax must agree.  At least n_min positions must
+    qualify -- so the check cannot pass vacuously: a broken kernel inflates the noise, fewer positions qualify, the count assert fails."""
+    t0 = time.time()
+    lg_ref, margins, arg_ref = fd.teacher_forced_reference(w, cfg, ids, feats, cont)
+    print(f"[{tag}] fp32 oracle, one causal pass over {len(ids) + len(cont)} tokens: {time.time() - t0:.0f}s")
+    kv, nxt, lg = m.prefill([ids], feats.to(dtype), len(ids) + len(cont) + 8, want_logits=True)
+    errs, checked, agree_all = [], 0, 0
+    worst = 0.0
+    for i in range(len(cont) + 1):
+        d = lg[0].float().cpu() - lg_ref[i]
+        e = float(d.double().norm() / lg_ref[i].double().norm())
+        sigma = float(d.std())
+        errs.append(e)
+        got = int(lg[0].argmax())
+        agree_all += int(got == arg_ref[i])
+        if margins[i] > sigmas * sigma:
+            checked += 1
+            assert got == arg_ref[i], (tag, i, got, arg_ref[i], margins[i], sigma)
+        worst = max(worst, e)
+        if i < len(cont):
+            nxt, lg = m.decode_step(kv, torch.tensor([cont[i]], dtype=torch.int32, device=DEV), want_logits=True)
+    e_ref = _yard(golden_dir, yard_case, lg_ref[0])
+    print(f"[{tag}] prefill logits rel err {errs[0]:.3e}, worst of {len(errs)} teacher-forced positions {worst:.3e}; the reference's own "
+          f"16-bit run (prefill): {e_ref:.3e}; argmax checked at {checked} positions (margin > {sigmas} sigma), all agree; "
+          f"unfiltered agreement {agree_all}/{len(errs)}")
+    assert checked >= n_min, f"only {checked} positions had a margin above {sigmas} sigma of the measured noise"
+    assert errs[0] < YARD_FACTOR * e_ref and worst < 1.6 * YARD_FACTOR * e_ref, (errs[0], worst, e_ref)
+    return errs[0], worst, e_ref
+
+
+def test_7b_full_depth_bf16_teacher_forced(ctx, golden_dir):
+    """The BENCHED dtype at full depth (bench.py's headline line is bf16): 32 layers, bf16 weights and activations, 441-token prompt with 356
+    video rows, then 96 teacher-forced positions against the fp32 oracle on the same bf16-valued weights.  bf16 carries 8x fp16's rounding, so
+    a free-running 16-token comparison would hit near-ties whatever the seed; instead every position is compared and the argmax is
+    asserted wherever the oracle's margin clears 6 sigma of the measured noise, at least 12 such positions required."""
+    c, cfg, w, m = _build("7b", torch.bfloat16)
+    ids, feats = fd.make_prompt(cfg, c["prompt_seed"])
+    cont = fd.teacher_tokens(cfg, c["prompt_seed"], fd.N_TEACHER["7b"])
+    _teacher_forced_check("7b bf16", m, cfg, w, ids, feats, cont, torch.bfloat16, golden_dir, "7b_bf16")
+
+
+def test_13b_full_depth_fp8_weights_bf16_teacher_forced(ctx, golden_dir):
+    """BASELINE config 5 as bench.py runs it: 13B shapes, 40 layers, e4m3 weights, BF16 activations.  Oracle = fp32 on the dequantised weights
+    the library reports; same noise-aware teacher-forced check as the 7B bf16 case over 160 positions."""
+    c, cfg, w, m = _build("13b", torch.bfloat16)
+    m.quantize_weights_fp8()
+    for k in list(w):
+        if k == "lm_head.weight" or any(f".{n}." in k for n in ollm.FP8_KEYS):
+            w[k] = m.get_weight(k).to(torch.bfloat16).cpu()
+    gc.collect()
+    ids, feats = fd.make_prompt(cfg, c["prompt_seed"])
+    cont = fd.teacher_tokens(cfg, c["prompt_seed"], fd.N_TEACHER["13b"])
+    _teacher_forced_check("13b fp8 bf16", m, cfg, w, ids, feats, cont, torch.bfloat16, golden_dir, "13b_fp8_bf16")

@@ -406,3 +406,29 @@ def test_greedy_pick_takes_the_first_index_on_ties(ctx):
     m2 = _model(cfg, w, torch.float16)
     kv, nxt, lg = m2.prefill([ids], None, 64, want_logits=True)
     assert bool(torch.isnan(lg[0, 0])) and nxt.tolist() == [1]
+
+
+def test_plain_decode_step_after_an_eos_terminated_run(ctx, golden_dir):
+    """A cache whose `done` flag was set by decode_greedy (EOS hit) must still serve plain pgv_llm_decode steps: the single-step entry
+    records nothing and ignores `done` (it used to emit eos = -1 as the next token and then read embed[-H]).  The step after the run must
+    equal the step of a fresh run that never saw EOS."""
+    g = np.load(os.path.join(golden_dir, "llama_tiny.npz"))
+    cfg = synth.LLAMA_TINY
+    w = synth.make_llama_weights(cfg, seed=int(g["lin_weight_seed"]), head_std=float(g["head_std"]))
+    m = _model(cfg, w, torch.float16)
+    ids, toks_ref = g["lin_ids"].tolist(), g["lin_tokens"].tolist()
+    feats = torch.from_numpy(g["lin_feats"]).half()
+    kv, nxt, _ = m.prefill([ids], feats, 64)
+    assert int(nxt[0]) == toks_ref[0]
+    got = m.decode_greedy(kv, nxt, 4, eos_id=toks_ref[2])[0].tolist()          # EOS = the token of step 2: the run goes sticky from there
+    assert got == [toks_ref[1], toks_ref[2], toks_ref[2], toks_ref[2]]
+    # the cache now holds ids + toks_ref[0..2] + two sticky EOS tokens at positions the reference would never produce; what matters here:
+    # a plain step with an explicit token works, returns a real token id and the logits of exactly that context
+    nxt2, lg = m.decode_step(kv, torch.tensor([toks_ref[3]], dtype=torch.int32, device=DEV), want_logits=True)
+    assert 0 <= int(nxt2[0]) < cfg.vocab and int(nxt2[0]) == int(lg[0].argmax())
+    o = ollm.LlamaOracle(w, cfg)
+    o.prefill(ids, feats.float(), cfg.vocab - 2, cfg.vocab - 1, cfg.vocab - 3)
+    for t in [toks_ref[0], toks_ref[1], toks_ref[2], toks_ref[2]]:
+        o.step(t)
+    want = o.step(toks_ref[3])[0]
+    assert rel(lg[0], want) < 1e-3

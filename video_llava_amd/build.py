@@ -40,8 +40,10 @@ LAB_OBJ = os.path.join(HERE, "_build_lab")
 LAB_LIB = os.path.join(HERE, "libpgv_lab.so")     # -DPGV_LAB: timing-ablation switches compiled in (results are garbage under them); never loaded by the product
 
 
-def build_variant(name: str, defines: list[str], verbose: bool = False) -> str:
-    """Lab A/B builds: libpgv_<name>.so compiled with extra -D flags (objects under _build_<name>/).  Bound only by scripts/lab/with_lib.py."""
+def build_variant(name: str, defines: list[str], verbose: bool = False, csrc: str | None = None) -> str:
+    """Lab A/B builds: libpgv_<name>.so compiled with extra -D flags (objects under _build_<name>/), optionally from another source
+    directory (e.g. `git worktree` of an older commit's csrc).  Bound only by scripts/lab/with_lib.py."""
+    CSRC = csrc or globals()["CSRC"]
     odir = os.path.join(HERE, f"_build_{name}")
     os.makedirs(odir, exist_ok=True)
     lib = os.path.join(HERE, f"libpgv_{name}.so")
@@ -54,7 +56,7 @@ def build_variant(name: str, defines: list[str], verbose: bool = False) -> str:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
         return opath
     with concurrent.futures.ThreadPoolExecutor(max_workers=8) as ex:
-        objs = list(ex.map(one, sources_present()))
+        objs = list(ex.map(one, [s_ for s_ in SOURCES if os.path.exists(os.path.join(CSRC, s_))]))
     r = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr}")

@@ -47,6 +47,9 @@ extern "C" void pgv_ctx_destroy(pgv_ctx* ctx) {
     if (ctx->zero_bias) (void)hipFree(ctx->zero_bias);
     if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
     if (ctx->ws_event) (void)hipEventDestroy(ctx->ws_event);
+    if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     for (auto& f : ctx->fam)
         for (auto e : f.ev) (void)hipEventDestroy(e);
     delete ctx;
@@ -56,11 +59,9 @@ extern "C" size_t pgv_ctx_workspace_bytes(const pgv_ctx* ctx) { return ctx ? ctx
 
 int pgv_ws_reserve(pgv_ctx* ctx, size_t bytes, hipStream_t s) {
     ctx->ws_off = 0;
-    if (ctx->ws_stream_valid && ctx->ws_stream != s) {
-        if (!ctx->ws_event) PGV_HIP(hipEventCreateWithFlags(&ctx->ws_event, hipEventDisableTiming));
-        if (hipEventRecord(ctx->ws_event, ctx->ws_stream) == hipSuccess) PGV_HIP(hipStreamWaitEvent(s, ctx->ws_event, 0));
-        else (void)hipGetLastError();          // the previous stream no longer exists: its work was drained when it was destroyed
-    }
+    // Ordering against the previous user of the arena: it recorded ws_event on ITS stream when it finished enqueueing (pgv_ws_release), so a
+    // call on another stream only waits on that event -- the old stream handle is never touched again (it may have been destroyed since).
+    if (ctx->ws_stream_valid && ctx->ws_stream != s && ctx->ws_event) PGV_HIP(hipStreamWaitEvent(s, ctx->ws_event, 0));
     ctx->ws_stream = s; ctx->ws_stream_valid = true;
     if (bytes <= ctx->ws_bytes) return PGV_OK;
     // grow: wait for queued work that may still read the old arena
@@ -75,6 +76,12 @@ int pgv_ws_reserve(pgv_ctx* ctx, size_t bytes, hipStream_t s) {
         return PGV_ENOMEM;
     }
     ctx->ws_bytes = want;
+    return PGV_OK;
+}
+
+int pgv_ws_release(pgv_ctx* ctx, hipStream_t s) {
+    if (!ctx->ws_event) PGV_HIP(hipEventCreateWithFlags(&ctx->ws_event, hipEventDisableTiming));
+    PGV_HIP(hipEventRecord(ctx->ws_event, s));
     return PGV_OK;
 }
 

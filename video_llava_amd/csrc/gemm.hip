@@ -199,13 +199,21 @@ __device__ __forceinline__ void epilogue_w4(const KArgs& p, f32x16_t (&acc)[4][4
                 *(f32x4_t*)(stg + l31 * 256 + (((8 * jj + 2 * g + hi) ^ (l31 & 15)) << 4)) = v;
             }
         __builtin_amdgcn_wave_barrier();
+        // read side: all eight row reads of the piece are issued before the first is consumed (left to itself hipcc issues read, wait, finish,
+        // store, next read: eight exposed LDS round trips per piece -- the epilogue time did not depend on the bytes stored at all)
+        f32x4_t dv[8], uv[SWIGLU ? 8 : 1];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int row = r * 4 + rrow;
+            dv[r] = *(const f32x4_t*)(stg + row * 256 + ((rc ^ (row & 15)) << 4));
+            if constexpr (SWIGLU) uv[r] = *(const f32x4_t*)(stg + row * 256 + (((rc ^ 8) ^ (row & 15)) << 4));     // partner chunk: up (for rc < 8)
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
             const unsigned o = voff[jp] + (i * 32 + r * 4) * rowpitch;
-            f32x4_t d = *(const f32x4_t*)(stg + row * 256 + ((rc ^ (row & 15)) << 4));
+            f32x4_t d = dv[r];
             if constexpr (SWIGLU) {
-                const f32x4_t u = *(const f32x4_t*)(stg + row * 256 + (((rc ^ 8) ^ (row & 15)) << 4));     // partner chunk: up (for rc < 8)
+                const f32x4_t u = uv[r];
                 __builtin_amdgcn_raw_buffer_store_b64(pack4<T>(silu_f(d[0]) * u[0], silu_f(d[1]) * u[1], silu_f(d[2]) * u[2], silu_f(d[3]) * u[3]), rsrc, o, 0, 0);
             } else {
                 if constexpr (LN_IN) {
@@ -327,7 +335,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4(KArgs p) {
     };
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
-    using NoDma = std::integral_constant<int, -1>;
+    using NoDma [[maybe_unused]] = std::integral_constant<int, -1>;
     using First = std::true_type;
     using Later = std::false_type;
     rebaseA(blockIdx.x); rebaseW(blockIdx.x);
@@ -387,7 +395,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4(KArgs p) {
     using DmaA1 = std::integral_constant<int, 1>;
     using DmaW0 = std::integral_constant<int, 2>;
     using DmaW1 = std::integral_constant<int, 3>;
-    using DmaWall = std::integral_constant<int, 4>;
+    using DmaWall [[maybe_unused]] = std::integral_constant<int, 4>;
 
     // prologue: A0 W0 A1 and the first half of W1 (slots 0 1 2 3); the loop continues with W1's second half
 #pragma unroll

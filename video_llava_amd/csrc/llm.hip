@@ -427,6 +427,7 @@ extern "C" int pgv_llm_prefill(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, const int32
     for (int b = 0; b < kv->B; ++b) kv->h_len[b] = b < B ? h_seq_lens[b] : 0;
     kv->active = B;
     PGV_HIP(hipGetLastError());
+    PGV_TRY(pgv_ws_release(ctx, s));
     return PGV_OK;
 }
 
@@ -613,5 +614,6 @@ extern "C" int pgv_projector(pgv_ctx* ctx, int dtype, int depth, const void* con
         PGV_TRY(pgv_launch_gemm(ctx, dtype, g, s));
         in = g.C; K = hidden;
     }
+    if (depth > 1) PGV_TRY(pgv_ws_release(ctx, s));
     return PGV_OK;
 }

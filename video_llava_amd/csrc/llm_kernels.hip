@@ -754,8 +754,8 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const typename T::
 }
 
 // ---------------------------------------------------------------------------------------------
-// greedy pick (first index wins ties, like torch.argmax on CPU) + bookkeeping: advance != 0 also does pos[b]++,
-// hist[b][step[b]++] = token, EOS stickiness.
+// greedy pick (first index wins ties, like torch.argmax on CPU) + bookkeeping: advance bit 0 does pos[b]++, bit 1 does
+// hist[b][step[b]++] = token and EOS stickiness.
 // ---------------------------------------------------------------------------------------------
 // greedy pick from the lm_head GEMV's per-workgroup candidates (GemvArgs::amax_*): same result as a scan of the full logits
 // (largest value, smallest index on ties, NaN never), 16x fewer values to scan.
@@ -784,13 +784,16 @@ __global__ __launch_bounds__(256) void argmax_parts_kernel(const float* __restri
         for (int i = 1; i < 4; ++i)
             if (sv[i] > best || (sv[i] == best && si[i] < bi)) { best = sv[i]; bi = si[i]; }
         int tok = bi < V ? bi : 0;
-        if (advance) {
+        // flags (llm.hip AM_*): 1 = advance the position, 2 = record (token history + EOS stickiness).  A plain pgv_llm_decode step passes 1
+        // only: it must neither append to the history nor look at a `done` flag a previous decode_greedy / decode_sample run left set
+        // (tok = eos = -1 would index embed[-H] on the next step).
+        if (advance & 2) {
             if (done[b]) tok = eos;
             else if (eos >= 0 && tok == eos) done[b] = 1;
             hist[(size_t)b * hist_stride + step[b]] = tok;
             step[b] += 1;
-            pos[b] += 1;
         }
+        if (advance & 1) pos[b] += 1;
         next[b] = tok;
     }
 }
@@ -936,13 +939,13 @@ __global__ __launch_bounds__(1024) void sample_kernel(SampleArgs p) {
     else if (any != 0ull) sl = 63 - __builtin_clzll(any);
     if (lane == 0) {
         int tok = (any != 0ull) ? i0 + sl : 0;               // all-NaN / empty rows: token 0 rather than an out-of-range id
-        if (p.advance) {
+        if (p.advance & 2) {                                  // AM_RECORD (see argmax_parts_kernel)
             if (p.done[b]) tok = p.eos;
             else if (p.eos >= 0 && tok == p.eos) p.done[b] = 1;
             p.hist[(size_t)b * p.hist_stride + p.step[b]] = tok;
             p.step[b] += 1;
-            p.pos[b] += 1;
         }
+        if (p.advance & 1) p.pos[b] += 1;
         p.next[b] = tok;
     }
 }

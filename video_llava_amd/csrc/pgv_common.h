@@ -57,16 +57,20 @@ struct pgv_ctx {
     bool prof = false;
     pgv_prof_family fam[PGV_NFAMILY];
     hipStream_t cap_stream = nullptr;   // used only to capture decode graphs
-    hipStream_t ws_stream = nullptr;    // stream of the last call that carved the arena (the arena is stream-ordered: one stream at a time)
+    hipStream_t ws_stream = nullptr;    // stream of the last call that carved the arena: compared by value only, never used after that call
     bool ws_stream_valid = false;
-    hipEvent_t ws_event = nullptr;
+    hipEvent_t ws_event = nullptr;      // recorded on the user's stream at the end of every arena-using call (pgv_ws_release)
+    hipStream_t aux_stream = nullptr;   // second lane of the two-lane ViT pass (vit.hip): forked from / joined into the caller's stream by events
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     float* zero_bias = nullptr;         // PGV_ZERO_BIAS_LEN zeros: stands in for a null bias so the persistent GEMM epilogue is branch-free
 };
 
 // Reserve the arena for a call enqueued on `s` (may hipMalloc: never call inside graph capture).  The arena is reused by every call, so
-// the only ordering between two users is stream order: when `s` differs from the stream of the previous user, `s` is made to wait for
-// everything that stream had queued (one event), which keeps two torch streams on one context correct (if serialised).
+// the only ordering between two users is stream order: every user ends with pgv_ws_release (an event recorded on its own stream), and when
+// `s` differs from the stream of the previous user, `s` first waits for that event -- two torch streams on one context stay correct (if
+// serialised) and a stream handle is never used after the call it was passed to.
 int pgv_ws_reserve(pgv_ctx* ctx, size_t bytes, hipStream_t s);
+int pgv_ws_release(pgv_ctx* ctx, hipStream_t s);
 // Bump allocate (256-B aligned) from the reserved arena; nullptr if exhausted.
 void* pgv_ws_alloc(pgv_ctx* ctx, size_t bytes);
 inline void pgv_ws_reset(pgv_ctx* ctx) { ctx->ws_off = 0; }

@@ -154,6 +154,12 @@ static bool ln_fold_enabled() {
     return v == 1;
 }
 
+static bool vit_lanes_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("PGV_VIT_LANES"); v = (e && e[0] == '1') ? 0 : 1; }     // PGV_VIT_LANES=1: single lane (A/B switch, identical results)
+    return v == 1;
+}
+
 extern "C" int pgv_vit_forward(pgv_ctx* ctx, pgv_vit* v, const void* d_pixels, int T, int n_layers, void* d_hidden, void* stream) {
     PGV_CHECK(ctx && v && d_pixels && d_hidden, "pgv_vit_forward: null argument");
     PGV_CHECK(T > 0, "pgv_vit_forward: T must be positive (got %d)", T);
@@ -169,77 +175,123 @@ extern "C" int pgv_vit_forward(pgv_ctx* ctx, pgv_vit* v, const void* d_pixels, i
         }
         v->folded = true;
     }
-    const int Tc_max = T < v->max_chunk_frames ? T : v->max_chunk_frames;
+    // ---- lanes ----------------------------------------------------------------------------------------------------------------------
+    // A pass is a chain of ~160 dependent launches, each a persistent grid whose last round fills only part of the chip (N = 1024 GEMMs at
+    // 800 frames: 3216 tiles = 12.56 rounds of 256 CUs; one 100-frame clip: 404 tiles = 1.58 rounds).  With TWO lanes -- the frames split in
+    // halves, each half its own chain on its own stream and its own workspace -- the idle CUs of one lane's tail run the head of the other
+    // lane's next kernel.  Per-frame results do not depend on how frames are batched (bitwise; tests/test_gpu_vision.py), so the split is
+    // invisible in the output.  The second stream is forked from and joined back into the caller's stream with events.
+    const int lanes = (vit_lanes_enabled() && !ctx->prof && T >= 16) ? 2 : 1;     // per-launch profiling wants kernels alone on the chip
+    int lane_t0[2] = {0, 0}, lane_T[2] = {T, 0};
+    if (lanes == 2) { lane_T[0] = (T + 1) / 2; lane_t0[1] = lane_T[0]; lane_T[1] = T - lane_T[0]; }
+    const int Tc_max = lane_T[0] < v->max_chunk_frames ? lane_T[0] : v->max_chunk_frames;
     const size_t Mmax = (size_t)Tc_max * N;
     const int NP = C / 64;             // 64-column pieces of a residual row (partial statistics of the folded LayerNorm)
     const size_t b_resid = pgv_align(Mmax * C * 4), b_xn = pgv_align(Mmax * C * 2), b_qkv = pgv_align(Mmax * 3 * C * 2), b_ao = pgv_align(Mmax * C * 2),
                  b_h = pgv_align(Mmax * I * 2 > (size_t)Tc_max * P * ((size_t)v->Kp * 2 + C * 4) + 512 ? Mmax * I * 2 : (size_t)Tc_max * P * ((size_t)v->Kp * 2 + C * 4) + 512),
                  b_part = pgv_align(Mmax * NP * 8), b_stat = pgv_align(Mmax * 8);
-    PGV_TRY(pgv_ws_reserve(ctx, b_resid + b_xn + b_qkv + b_ao + b_h + b_part + b_stat, s));
-    float* resid = (float*)pgv_ws_alloc(ctx, b_resid);
-    char* xn = (char*)pgv_ws_alloc(ctx, b_xn);
-    char* qkv = (char*)pgv_ws_alloc(ctx, b_qkv);
-    char* ao = (char*)pgv_ws_alloc(ctx, b_ao);
-    char* hbuf = (char*)pgv_ws_alloc(ctx, b_h);
-    float* part = (float*)pgv_ws_alloc(ctx, b_part);
-    float* rowstat = (float*)pgv_ws_alloc(ctx, b_stat);
-    PGV_CHECK(resid && xn && qkv && ao && hbuf && part && rowstat, "pgv_vit_forward: workspace exhausted");
+    PGV_TRY(pgv_ws_reserve(ctx, (size_t)lanes * (b_resid + b_xn + b_qkv + b_ao + b_h + b_part + b_stat), s));
+    struct Lane { hipStream_t s; float* resid; char *xn, *qkv, *ao, *hbuf; float *part, *rowstat; int t0, T, done; } L[2];
+    for (int k = 0; k < lanes; ++k) {
+        L[k].resid = (float*)pgv_ws_alloc(ctx, b_resid);
+        L[k].xn = (char*)pgv_ws_alloc(ctx, b_xn);
+        L[k].qkv = (char*)pgv_ws_alloc(ctx, b_qkv);
+        L[k].ao = (char*)pgv_ws_alloc(ctx, b_ao);
+        L[k].hbuf = (char*)pgv_ws_alloc(ctx, b_h);
+        L[k].part = (float*)pgv_ws_alloc(ctx, b_part);
+        L[k].rowstat = (float*)pgv_ws_alloc(ctx, b_stat);
+        PGV_CHECK(L[k].resid && L[k].xn && L[k].qkv && L[k].ao && L[k].hbuf && L[k].part && L[k].rowstat, "pgv_vit_forward: workspace exhausted");
+        L[k].s = s; L[k].t0 = lane_t0[k]; L[k].T = lane_T[k]; L[k].done = 0;
+    }
+    if (lanes == 2) {
+        if (!ctx->aux_stream) PGV_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+        if (!ctx->ev_fork) PGV_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        if (!ctx->ev_join) PGV_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+        PGV_HIP(hipEventRecord(ctx->ev_fork, s));
+        PGV_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
+        L[1].s = ctx->aux_stream;
+    }
 
-    for (int t0 = 0; t0 < T; t0 += Tc_max) {
-        const int Tc = (T - t0) < Tc_max ? (T - t0) : Tc_max;
+    // one chunk (<= Tc_max frames) of a lane, phase by phase so that the two lanes' launches are enqueued alternately
+    auto embed = [&](Lane& ln, int t0, int Tc) -> int {
         const int M = Tc * N;
         const char* pix = (const char*)d_pixels + (size_t)t0 * 3 * S * S * 2;
         // patch conv as GEMM: [Tc*P, Kp] x [C, Kp]^T -> fp32 [Tc*P, C]
-        char* a0 = hbuf;
-        float* pe = (float*)(hbuf + pgv_align((size_t)Tc * P * v->Kp * 2));
-        PGV_TRY(pgv_launch_im2col(pix, a0, Tc, S, v->grid, v->cfg.patch, v->Kp, s));
+        char* a0 = ln.hbuf;
+        float* pe = (float*)(ln.hbuf + pgv_align((size_t)Tc * P * v->Kp * 2));
+        PGV_TRY(pgv_launch_im2col(pix, a0, Tc, S, v->grid, v->cfg.patch, v->Kp, ln.s));
         GemmArgs g{};
         g.A = a0; g.lda = v->Kp; g.W = v->patch_w; g.ldw = v->Kp; g.bias = nullptr; g.C = pe; g.ldc = C; g.M = Tc * P; g.N = C; g.K = v->Kp; g.epi = PGV_EPI_F32;
-        PGV_TRY(pgv_launch_gemm(ctx, v->dtype, g, s));
+        PGV_TRY(pgv_launch_gemm(ctx, v->dtype, g, ln.s));
         const bool f0 = fold && n_layers > 0;
-        PGV_TRY(pgv_launch_embed_ln(v->dtype, pe, v->cls, v->pos, v->pre_g, v->pre_b, v->cfg.eps, resid, M, N, C, f0 ? v->layers[0].ln1_g : nullptr, xn, rowstat, s));
-        for (int li = 0; li < n_layers; ++li) {
-            const VitLayer& l = v->layers[li];
-            if (fold) {
-                // LayerNorm has no launch of its own (gemm.hip, EPI_LN_*): xn = round16(resid * ln1_g), rowstat = (mean, rstd) of resid
-                g = GemmArgs{}; g.A = xn; g.lda = C; g.W = l.wqkv; g.ldw = C; g.bias = l.b2_qkv; g.C = qkv; g.ldc = 3 * C; g.M = M; g.N = 3 * C; g.K = C;
-                g.epi = PGV_EPI_LN_BIAS; g.rowstat = rowstat; g.colsum = l.s_qkv;
-                PGV_TRY(pgv_launch_gemm(ctx, v->dtype, g, s));
-                PGV_TRY(pgv_launch_vit_attn(ctx, v->dtype, qkv, 3 * C, ao, C, Tc, N, C, v->cfg.heads, s));
-                g = GemmArgs{}; g.A = ao; g.lda = C; g.W = l.wo; g.ldw = C; g.bias = l.bo; g.C = resid; g.ldc = C; g.M = M; g.N = C; g.K = C;
-                g.epi = PGV_EPI_BIAS_RESID_LNOUT; g.gnext = l.ln2_g; g.x16 = xn; g.ldx16 = C; g.stats_part = part;
-                PGV_TRY(pgv_launch_gemm(ctx, v->dtype, g, s));
-                PGV_TRY(pgv_launch_ln_stats(part, rowstat, M, NP, C, v->cfg.eps, s));
-                g = GemmArgs{}; g.A = xn; g.lda = C; g.W = l.w1; g.ldw = C; g.bias = l.b2_fc1; g.C = hbuf; g.ldc = I; g.M = M; g.N = I; g.K = C;
-                g.epi = PGV_EPI_LN_BIAS_QGELU; g.rowstat = rowstat; g.colsum = l.s_fc1;
-                PGV_TRY(pgv_launch_gemm(ctx, v->dtype, g, s));
-                g = GemmArgs{}; g.A = hbuf; g.lda = I; g.W = l.w2; g.ldw = I; g.bias = l.b2; g.C = resid; g.ldc = C; g.M = M; g.N = C; g.K = I;
-                if (li + 1 < n_layers) {
-                    g.epi = PGV_EPI_BIAS_RESID_LNOUT; g.gnext = v->layers[li + 1].ln1_g; g.x16 = xn; g.ldx16 = C; g.stats_part = part;
-                    PGV_TRY(pgv_launch_gemm(ctx, v->dtype, g, s));
-                    PGV_TRY(pgv_launch_ln_stats(part, rowstat, M, NP, C, v->cfg.eps, s));
-                } else {
-                    // the last executed layer feeds no LayerNorm: its "operand copy" with gamma = 1 is round16(resid) -- the hidden state itself,
-                    // written straight into the caller's buffer (no cast pass over the fp32 residual); the statistics are discarded
-                    g.epi = PGV_EPI_BIAS_RESID_LNOUT; g.gnext = v->ones; g.x16 = (char*)d_hidden + (size_t)t0 * N * C * 2; g.ldx16 = C; g.stats_part = part;
-                    PGV_TRY(pgv_launch_gemm(ctx, v->dtype, g, s));
-                }
-                continue;
-            }
-            PGV_TRY(pgv_launch_layernorm(v->dtype, resid, l.ln1_g, l.ln1_b, v->cfg.eps, xn, M, C, s));
-            g = GemmArgs{}; g.A = xn; g.lda = C; g.W = l.wqkv; g.ldw = C; g.bias = l.bqkv; g.C = qkv; g.ldc = 3 * C; g.M = M; g.N = 3 * C; g.K = C; g.epi = PGV_EPI_BIAS;
+        PGV_TRY(pgv_launch_embed_ln(v->dtype, pe, v->cls, v->pos, v->pre_g, v->pre_b, v->cfg.eps, ln.resid, M, N, C, f0 ? v->layers[0].ln1_g : nullptr, ln.xn, ln.rowstat, ln.s));
+        return PGV_OK;
+    };
+    auto layer = [&](Lane& ln, int t0, int Tc, int li) -> int {
+        const int M = Tc * N;
+        const VitLayer& l = v->layers[li];
+        float* resid = ln.resid; char *xn = ln.xn, *qkv = ln.qkv, *ao = ln.ao, *hbuf = ln.hbuf; float *part = ln.part, *rowstat = ln.rowstat;
+        hipStream_t s = ln.s;
+        GemmArgs g{};
+        if (fold) {
+            // LayerNorm has no launch of its own (gemm.hip, EPI_LN_*): xn = round16(resid * ln1_g), rowstat = (mean, rstd) of resid
+            g = GemmArgs{}; g.A = xn; g.lda = C; g.W = l.wqkv; g.ldw = C; g.bias = l.b2_qkv; g.C = qkv; g.ldc = 3 * C; g.M = M; g.N = 3 * C; g.K = C;
+            g.epi = PGV_EPI_LN_BIAS; g.rowstat = rowstat; g.colsum = l.s_qkv;
             PGV_TRY(pgv_launch_gemm(ctx, v->dtype, g, s));
             PGV_TRY(pgv_launch_vit_attn(ctx, v->dtype, qkv, 3 * C, ao, C, Tc, N, C, v->cfg.heads, s));
-            g = GemmArgs{}; g.A = ao; g.lda = C; g.W = l.wo; g.ldw = C; g.bias = l.bo; g.C = resid; g.ldc = C; g.M = M; g.N = C; g.K = C; g.epi = PGV_EPI_BIAS_RESID;
+            g = GemmArgs{}; g.A = ao; g.lda = C; g.W = l.wo; g.ldw = C; g.bias = l.bo; g.C = resid; g.ldc = C; g.M = M; g.N = C; g.K = C;
+            g.epi = PGV_EPI_BIAS_RESID_LNOUT; g.gnext = l.ln2_g; g.x16 = xn; g.ldx16 = C; g.stats_part = part;
             PGV_TRY(pgv_launch_gemm(ctx, v->dtype, g, s));
-            PGV_TRY(pgv_launch_layernorm(v->dtype, resid, l.ln2_g, l.ln2_b, v->cfg.eps, xn, M, C, s));
-            g = GemmArgs{}; g.A = xn; g.lda = C; g.W = l.w1; g.ldw = C; g.bias = l.b1; g.C = hbuf; g.ldc = I; g.M = M; g.N = I; g.K = C; g.epi = PGV_EPI_BIAS_QGELU;
+            PGV_TRY(pgv_launch_ln_stats(part, rowstat, M, NP, C, v->cfg.eps, s));
+            g = GemmArgs{}; g.A = xn; g.lda = C; g.W = l.w1; g.ldw = C; g.bias = l.b2_fc1; g.C = hbuf; g.ldc = I; g.M = M; g.N = I; g.K = C;
+            g.epi = PGV_EPI_LN_BIAS_QGELU; g.rowstat = rowstat; g.colsum = l.s_fc1;
             PGV_TRY(pgv_launch_gemm(ctx, v->dtype, g, s));
-            g = GemmArgs{}; g.A = hbuf; g.lda = I; g.W = l.w2; g.ldw = I; g.bias = l.b2; g.C = resid; g.ldc = C; g.M = M; g.N = C; g.K = I; g.epi = PGV_EPI_BIAS_RESID;
-            PGV_TRY(pgv_launch_gemm(ctx, v->dtype, g, s));
+            g = GemmArgs{}; g.A = hbuf; g.lda = I; g.W = l.w2; g.ldw = I; g.bias = l.b2; g.C = resid; g.ldc = C; g.M = M; g.N = C; g.K = I;
+            if (li + 1 < n_layers) {
+                g.epi = PGV_EPI_BIAS_RESID_LNOUT; g.gnext = v->layers[li + 1].ln1_g; g.x16 = xn; g.ldx16 = C; g.stats_part = part;
+                PGV_TRY(pgv_launch_gemm(ctx, v->dtype, g, s));
+                PGV_TRY(pgv_launch_ln_stats(part, rowstat, M, NP, C, v->cfg.eps, s));
+            } else {
+                // the last executed layer feeds no LayerNorm: its "operand copy" with gamma = 1 is round16(resid) -- the hidden state itself,
+                // written straight into the caller's buffer (no cast pass over the fp32 residual); the statistics are discarded
+                g.epi = PGV_EPI_BIAS_RESID_LNOUT; g.gnext = v->ones; g.x16 = (char*)d_hidden + (size_t)t0 * N * C * 2; g.ldx16 = C; g.stats_part = part;
+                PGV_TRY(pgv_launch_gemm(ctx, v->dtype, g, s));
+            }
+            return PGV_OK;
         }
-        if (!(fold && n_layers > 0)) PGV_TRY(pgv_launch_cast(v->dtype, resid, (char*)d_hidden + (size_t)t0 * N * C * 2, (size_t)M * C, s));
+        PGV_TRY(pgv_launch_layernorm(v->dtype, resid, l.ln1_g, l.ln1_b, v->cfg.eps, xn, M, C, s));
+        g = GemmArgs{}; g.A = xn; g.lda = C; g.W = l.wqkv; g.ldw = C; g.bias = l.bqkv; g.C = qkv; g.ldc = 3 * C; g.M = M; g.N = 3 * C; g.K = C; g.epi = PGV_EPI_BIAS;
+        PGV_TRY(pgv_launch_gemm(ctx, v->dtype, g, s));
+        PGV_TRY(pgv_launch_vit_attn(ctx, v->dtype, qkv, 3 * C, ao, C, Tc, N, C, v->cfg.heads, s));
+        g = GemmArgs{}; g.A = ao; g.lda = C; g.W = l.wo; g.ldw = C; g.bias = l.bo; g.C = resid; g.ldc = C; g.M = M; g.N = C; g.K = C; g.epi = PGV_EPI_BIAS_RESID;
+        PGV_TRY(pgv_launch_gemm(ctx, v->dtype, g, s));
+        PGV_TRY(pgv_launch_layernorm(v->dtype, resid, l.ln2_g, l.ln2_b, v->cfg.eps, xn, M, C, s));
+        g = GemmArgs{}; g.A = xn; g.lda = C; g.W = l.w1; g.ldw = C; g.bias = l.b1; g.C = hbuf; g.ldc = I; g.M = M; g.N = I; g.K = C; g.epi = PGV_EPI_BIAS_QGELU;
+        PGV_TRY(pgv_launch_gemm(ctx, v->dtype, g, s));
+        g = GemmArgs{}; g.A = hbuf; g.lda = I; g.W = l.w2; g.ldw = I; g.bias = l.b2; g.C = resid; g.ldc = C; g.M = M; g.N = C; g.K = I; g.epi = PGV_EPI_BIAS_RESID;
+        PGV_TRY(pgv_launch_gemm(ctx, v->dtype, g, s));
+        return PGV_OK;
+    };
+    auto tail = [&](Lane& ln, int t0, int Tc) -> int {
+        if (!(fold && n_layers > 0)) PGV_TRY(pgv_launch_cast(v->dtype, ln.resid, (char*)d_hidden + (size_t)t0 * N * C * 2, (size_t)Tc * N * C, ln.s));
+        return PGV_OK;
+    };
+    while (L[0].done < L[0].T || (lanes == 2 && L[1].done < L[1].T)) {
+        int ct0[2], cT[2];
+        for (int k = 0; k < lanes; ++k) {
+            ct0[k] = L[k].t0 + L[k].done;
+            cT[k] = (L[k].T - L[k].done) < Tc_max ? (L[k].T - L[k].done) : Tc_max;
+        }
+        for (int k = 0; k < lanes; ++k) if (cT[k] > 0) PGV_TRY(embed(L[k], ct0[k], cT[k]));
+        for (int li = 0; li < n_layers; ++li)
+            for (int k = 0; k < lanes; ++k) if (cT[k] > 0) PGV_TRY(layer(L[k], ct0[k], cT[k], li));
+        for (int k = 0; k < lanes; ++k) if (cT[k] > 0) { PGV_TRY(tail(L[k], ct0[k], cT[k])); L[k].done += cT[k]; }
     }
+    if (lanes == 2) {
+        PGV_HIP(hipEventRecord(ctx->ev_join, ctx->aux_stream));
+        PGV_HIP(hipStreamWaitEvent(s, ctx->ev_join, 0));
+    }
+    PGV_TRY(pgv_ws_release(ctx, s));
     PGV_HIP(hipGetLastError());
     return PGV_OK;
 }
