@@ -57,6 +57,11 @@ def parse():
     ap.add_argument("--dry", action="store_true",
                     help="no GPU work: every rank fills its shard's answer slots with a deterministic token pattern, then the real barrier / all-gather / "
                          "max-over-ranks / JSON path runs over gloo -- the CPU-testable skeleton of the N > 1 run (never a performance number)")
+    ap.add_argument("--no-runner", action="store_true",
+                    help="skip the runner-level measurement (side field `runner`: synthetic .npy clips on local disk through "
+                         "video_llava_amd.eval.run_inference_qa_activitynet.run_inference -- file discovery, frame sampling, tokenisation, "
+                         "detokenisation and the JSON dump included)")
+    ap.add_argument("--runner-groups", type=int, default=3, help="groups of --clips-per-gpu clips the runner measurement answers (after one warm-up group)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-port", action="store_true", help="additionally time this repo's own CPU oracle (reported under cpu_baseline.port)")
     ap.add_argument("--overlap-vision", action="store_true",
@@ -84,6 +89,93 @@ def make_prompts(n, vocab, video_rows, seed):
         out.append([1] + rng.integers(3, vocab - 3, 70 + q).tolist() + [START] + [PATCH] * video_rows + [END]
                    + rng.integers(3, vocab - 3, 6).tolist())
     return out
+
+
+class BenchTokenizer:
+    """Word-level synthetic tokenizer with the four calls the path makes (no tokenizer files offline): one id per word (two for words longer
+    than six characters, about what the LLaMA tokenizer yields on English prompts), the three video tokens at the top of the vocabulary."""
+
+    def __init__(self, vocab):
+        self.vocab = vocab
+        self.special = {"<vid_patch>": vocab - 3, "<vid_start>": vocab - 2, "<vid_end>": vocab - 1}
+
+    def _encode(self, text):
+        import re
+        ids = [1]
+        for piece in re.findall(r"<vid_patch>|<vid_start>|<vid_end>|[^\s<]+|<", text):
+            if piece in self.special:
+                ids.append(self.special[piece])
+                continue
+            h = sum((i + 1) * ord(c) for i, c in enumerate(piece))
+            ids.append(3 + h % (self.vocab - 8))
+            if len(piece) > 6:
+                ids.append(3 + (h * 31 + 7) % (self.vocab - 8))
+        return ids
+
+    def __call__(self, x):
+        class R:
+            pass
+        r = R()
+        r.input_ids = [self._encode(t) for t in x] if isinstance(x, (list, tuple)) else self._encode(x)
+        return r
+
+    def batch_decode(self, ids, skip_special_tokens=True):
+        return [" ".join(str(int(t)) for t in row) for row in ids]
+
+
+QUESTION_WORDS = ("what is the person in the video doing while the dog runs across the yard and then jumps over a small fence near the house "
+                  "before the man picks up the ball and throws it again towards the trees").split()
+
+
+def runner_measurement(args, model, tower, video_rows, S, rank, world):
+    """Runner-level throughput: what a user of video_chatgpt/eval/run_inference_qa_activitynet.py sees.  Synthetic clips are written to local
+    disk as `v_<name>.npy` (uint8 [100, S, S, 3]), an ActivityNet-QA-shaped question / answer file pair is generated, and the package's runner
+    (`run_inference`: file discovery, frame sampling on a prefetch thread, ONE tower pass per group, batched prefill + decode, stop-string
+    handling, detokenisation, JSON dump) answers `--runner-groups` groups of `--clips-per-gpu` clips after one warm-up group."""
+    import shutil
+    import tempfile
+    from video_llava_amd.eval import run_inference_qa_activitynet as qa
+    B, T, NEW = args.clips_per_gpu, args.frames, args.new_tokens
+    rng = np.random.default_rng(77)
+    tmp = tempfile.mkdtemp(prefix="pgv_runner_")
+    try:
+        vd = os.path.join(tmp, "videos")
+        os.makedirs(vd)
+        n_files = 2 * B                                         # consecutive groups read different files
+        for i in range(n_files):
+            np.save(os.path.join(vd, f"v_clip{i:03d}.npy"), rng.integers(0, 256, (T, S, S, 3), dtype=np.uint8))
+
+        class IP:
+            crop_size = {"height": S, "width": S}
+        tok = BenchTokenizer(model.vocab_size)
+        components = (model, tower, tok, IP(), video_rows)
+
+        def run(n_groups, tag):
+            n = n_groups * B * world
+            qs = [{"video_name": f"clip{(i % n_files):03d}", "question": " ".join(rng.choice(QUESTION_WORDS, int(rng.integers(6, 16)))) + "?",
+                   "question_id": f"q{i}"} for i in range(n)]
+            with open(os.path.join(tmp, f"q_{tag}.json"), "w") as f:
+                json.dump(qs, f)
+            with open(os.path.join(tmp, f"a_{tag}.json"), "w") as f:
+                json.dump([{"answer": "yes"}] * n, f)
+            a = qa.parse_args(["--video_dir", vd, "--gt_file_question", os.path.join(tmp, f"q_{tag}.json"), "--gt_file_answers",
+                               os.path.join(tmp, f"a_{tag}.json"), "--output_dir", os.path.join(tmp, "out"), "--output_name", tag, "--model-name", "synthetic",
+                               "--projection_path", "synthetic", "--batch", str(B), "--max_new_tokens", str(NEW)])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = qa.run_inference(a, components=components)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            assert len(out) == n and all(len(o["pred"].split()) == NEW for o in out), "runner dropped samples or cut answers short"
+            return n, dt
+        run(1, "warm")
+        n, dt = run(args.runner_groups, "timed")
+        return {"videos_per_sec": n / dt, "seconds": dt, "clips": n, "groups": args.runner_groups, "clips_per_group": B,
+                "entry": "video_llava_amd.eval.run_inference_qa_activitynet.run_inference", "frames_source": f"{n_files} .npy files on local disk (page cache)",
+                "includes": "file discovery, frame sampling (prefetch thread, pinned), upload, one tower pass per group, prefill, decode, stop handling, "
+                            "detokenisation, JSON dump"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 PMC_PREFIX = {"gemm": "gemm_w4", "vit_attn": "vit_attn_kernel", "llm_prefill_attn": "prefill_attn_kernel",
@@ -580,6 +672,10 @@ def main():
             t1 = time.perf_counter(); one_clip(); ts.append(time.perf_counter() - t1)
         latency = {"clips": 1, "frames": T, "new_tokens": NEW, "seconds_median": sorted(ts)[1], "seconds_min": min(ts),
                    "videos_per_sec_batch1": 1.0 / sorted(ts)[1]}
+    runner = None
+    if not args.no_runner and args.workload == "full" and world == 1:
+        runner = runner_measurement(args, model, tower, video_rows, S, rank, world)
+        runner["ratio_to_value"] = runner["videos_per_sec"] / value
     if world > 1:
         torch.distributed.barrier()
     clip_feat_tflops = B * T * VIT_FLOP_PER_FRAME_23L[S] / (vit_ms * 1e-3) / 1e12
@@ -683,6 +779,8 @@ def main():
             line["pcie_inclusive"] = pcie
         if latency:
             line["latency_b1"] = latency
+        if runner:
+            line["runner"] = runner
         if overlap:
             line["overlap_vision"] = overlap
         if fam:

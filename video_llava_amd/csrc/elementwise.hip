@@ -69,13 +69,14 @@ int launch_norm(const float* x, const float* g, const float* b, float eps, void*
 // -> fp32 residual stream (= hidden_states[0]).
 // ---------------------------------------------------------------------------------------------
 // When `gnext` is given (the tower runs at least one layer) the kernel is also the first PRODUCER of the folded LayerNorm (gemm.hip, EPI_LN_*):
-// x16 = round16(out * gnext) and rowstat = (mean, rstd) of the OUTPUT row, so layer 0's qkv GEMM needs no LayerNorm launch.
+// x16 = round16((out - mean) * gnext), rowstat = (0, rstd) and rowmean = mean of the OUTPUT row (the centred form: here the centre IS the row's
+// own mean, so the consumer's mean correction is zero), and layer 0's qkv GEMM needs no LayerNorm launch.
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__ pe, const float* __restrict__ cls,
                                                        const float* __restrict__ pos, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, float* __restrict__ out,
                                                        int rows, int tokens, const float* __restrict__ gnext, char* __restrict__ x16,
-                                                       float* __restrict__ rowstat) {
+                                                       float* __restrict__ rowstat, float* __restrict__ rowmean) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -117,26 +118,42 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const float* __restrict__
 #pragma unroll
         for (int e = 0; e < 4; ++e) { const float d = v[i][e] - m2; q += d * d; }
     const float rstd2 = rsqrtf(wave_sum(q) * (1.0f / cols) + eps);
-    if (lane == 0) *(f32x2_t*)(rowstat + (size_t)row * 2) = f32x2_t{m2, rstd2};
+    if (lane == 0) { *(f32x2_t*)(rowstat + (size_t)row * 2) = f32x2_t{0.f, rstd2}; rowmean[row] = m2; }
     u32x2_t* xr = (u32x2_t*)(x16 + (size_t)row * cols * 2);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const f32x4_t g = ((const f32x4_t*)gnext)[i * 64 + lane];
-        xr[i * 64 + lane] = pack4<T>(v[i][0] * g[0], v[i][1] * g[1], v[i][2] * g[2], v[i][3] * g[3]);
+        xr[i * 64 + lane] = pack4<T>((v[i][0] - m2) * g[0], (v[i][1] - m2) * g[1], (v[i][2] - m2) * g[2], (v[i][3] - m2) * g[3]);
     }
 }
 
-// Folded LayerNorm, between producer and consumer: per-row partial (sum, sum of squares) over NP 64-column pieces ([NP][rows][2]) -> (mean, rstd).
-// var = E[x^2] - mean^2 in fp32 (the CLIP residual's row mean is small against its spread; the two-pass form would need the row again).
-__global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__ part, float* __restrict__ rowstat, int rows, int np, float inv_cols, float eps) {
+// Folded LayerNorm, between producer and consumer.  The producer GEMM works on the row CENTRED at c = rowmean[row] (the row's mean before this
+// sublayer's update): per-row partial (sum, sum of squares) of (x - c) over NP 64-column pieces ([NP][rows][2]) -> delta = mean(x) - c, rstd;
+// rowstat = (delta, rstd) for the consumer GEMM, rowmean <- c + delta for the next producer.  var = E[(x-c)^2] - delta^2 in fp32: the
+// cancellation involves only how far the mean MOVED in one sublayer, not the mean itself, so rows whose mean dominates their spread are as
+// accurate as zero-mean rows (tests/test_gpu_vision.py::test_folded_layernorm_mean_dominated_rows).
+__global__ __launch_bounds__(256) void ln_stats_kernel(const float* __restrict__ part, float* __restrict__ rowstat, float* __restrict__ rowmean,
+                                                       const float* __restrict__ cshift, int rows, int np, float inv_cols, float eps) {
     const int row = blockIdx.x * 256 + threadIdx.x;
     if (row >= rows) return;
     const f32x2_t* p = (const f32x2_t*)part + row;               // piece-major [np][rows][2]: coalesced across the rows of a wave
     float s1 = 0.f, s2 = 0.f;
     for (int i = 0; i < np; ++i) { const f32x2_t v = p[(size_t)i * rows]; s1 += v[0]; s2 += v[1]; }
-    const float mean = s1 * inv_cols;
-    const float var = fmaxf(s2 * inv_cols - mean * mean, 0.f);
-    *(f32x2_t*)(rowstat + (size_t)row * 2) = f32x2_t{mean, rsqrtf(var + eps)};
+    const float delta = s1 * inv_cols;
+    const float var = fmaxf(s2 * inv_cols - delta * delta, 0.f);
+    *(f32x2_t*)(rowstat + (size_t)row * 2) = f32x2_t{delta, rsqrtf(var + eps)};
+    rowmean[row] += delta + (cshift ? *cshift : 0.f);       // the producer centred at rowmean + cshift
+}
+
+// mean of a vector (fp32) -> one device scalar (the data-independent shift of the row mean a biased GEMM applies; fixed-order reduction)
+__global__ __launch_bounds__(256) void vec_mean_kernel(const float* __restrict__ x, int n, float* __restrict__ out) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += x[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *out = ((sh[0] + sh[1]) + (sh[2] + sh[3])) / (float)n;
 }
 
 // Folded LayerNorm, load time: for a consumer weight W [N, K] (row-major 16-bit) with bias b and the LayerNorm parameters (gamma, beta) in front of it:
@@ -279,14 +296,19 @@ int pgv_launch_rmsnorm(int dtype, const float* x, const float* g, float eps, voi
     return PGV_OK;
 }
 int pgv_launch_embed_ln(int dtype, const float* pe, const float* cls, const float* pos, const float* g, const float* b, float eps, float* out,
-                        int rows, int tokens, int cols, const float* gnext, void* x16, float* rowstat, hipStream_t s) {
+                        int rows, int tokens, int cols, const float* gnext, void* x16, float* rowstat, float* rowmean, hipStream_t s) {
     PGV_CHECK(cols == 1024, "embed_ln: CLIP width must be 1024 (got %d)", cols);
+    PGV_CHECK(gnext == nullptr || (x16 && rowstat && rowmean), "embed_ln: the folded-LayerNorm producer needs x16 / rowstat / rowmean");
     PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((embed_ln_kernel<T, 4>), dim3((rows + 3) / 4), dim3(256), 0, s, pe, cls, pos, g, b, eps, out, rows, tokens,
-                                                    gnext, (char*)x16, rowstat));
+                                                    gnext, (char*)x16, rowstat, rowmean));
     return PGV_OK;
 }
-int pgv_launch_ln_stats(const float* part, float* rowstat, int rows, int np, int cols, float eps, hipStream_t s) {
-    hipLaunchKernelGGL(ln_stats_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, part, rowstat, rows, np, 1.0f / (float)cols, eps);
+int pgv_launch_ln_stats(const float* part, float* rowstat, float* rowmean, const float* cshift, int rows, int np, int cols, float eps, hipStream_t s) {
+    hipLaunchKernelGGL(ln_stats_kernel, dim3((rows + 255) / 256), dim3(256), 0, s, part, rowstat, rowmean, cshift, rows, np, 1.0f / (float)cols, eps);
+    return PGV_OK;
+}
+int pgv_launch_vec_mean(const float* x, int n, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(vec_mean_kernel, dim3(1), dim3(256), 0, s, x, n, out);
     return PGV_OK;
 }
 int pgv_launch_ln_fold(int dtype, const void* W, const float* bias, const float* gamma, const float* beta, float* colsum, float* bias2, int N, int K, hipStream_t s) {

@@ -32,10 +32,10 @@ struct KArgs {
     const float* colsum;    // consumer: [N] s_n = sum_k gamma_k W[n,k]
     const float* gnext;     // producer: [N] gamma of the LayerNorm that follows
     char* x16; int ldx16;   // producer: 16-bit copy round16(resid * gnext), row stride ldx16 elements
-    float* stats_part;      // producer: [N/64][M][2] partial (sum, sum of squares) of the new residual row over each 64-column piece
-#ifdef PGV_LAB
-    int stagger_ticks;      // lab: start delay unit (10 ns ticks), PGV_GEMM_STAGGER
-#endif
+    float* stats_part;      // producer: [N/64][M][2] partial (sum, sum of squares) of the CENTRED new residual row over each 64-column piece
+    const float* rowmean;   // producer: [M] mean of each row before this sublayer (null: centre 0 -- the plain 16-bit copy of the last layer)
+    const float* cshift;    // producer: device scalar added to rowmean to form the centre: mean(bias) of this GEMM, the data-independent part of
+                            // how far the sublayer moves the row mean (null = 0)
 };
 
 // Internal epilogues of the CLIP tower (not part of the public pgv_epi enum).  LayerNorm has no launch of its own:
@@ -46,6 +46,13 @@ struct KArgs {
 //   out[m,n] = rstd_m (acc[m,n] - mean_m s_n) + b'_n,   s_n = sum_k gamma_k W[n,k],  b'_n = b_n + sum_k beta_k W[n,k]  (fp32, at load time).
 // No weight is modified (gamma rides on the activation side), the statistics come from the fp32 residual; the 16-bit rounding moves from
 // after the normalisation to before it (same relative size).  Saves the read of the fp32 residual + the launch of every LayerNorm.
+// CENTRED form (round 3): the identity holds for x - c with any per-row c,
+//   LN(x) W^T + b = rstd ((x - c) gamma) W^T - rstd (mu - c) (W gamma) + (b + W beta),
+// and the producer uses c = the row's mean BEFORE its own update (rowmean, maintained by ln_stats_kernel) + mean(bias of this GEMM) (the
+// data-independent part of the update; what remains, a_row . mean_n W[n,:], is small): x16 = round16((resid - c) gamma_next),
+// partial sums of (resid - c); the consumer is unchanged with rowstat = (mu - c, rstd).  The operand that is rounded to 16 bits now has the
+// magnitude of the row's SPREAD whatever its mean, so mean-dominated rows (|mu| >> sigma) lose nothing -- the uncentred form carried
+// |mu| / sigma times the rounding error of the normalised operand and was only safe because random-init CLIP rows are zero-mean.
 enum { EPI_LN_BIAS = 8, EPI_LN_BIAS_QGELU = 9, EPI_BIAS_RESID_LNOUT = 10 };
 
 // Sum over each aligned group of 16 lanes, every lane receiving a BIT-IDENTICAL total: a butterfly of exchanges (quad_perm [1,0,3,2],
@@ -130,13 +137,15 @@ __device__ __forceinline__ void epilogue_w4(const KArgs& p, f32x16_t (&acc)[4][4
     f32x4_t bv[2];
     f32x4_t sv[2];                                             // LN_IN: column sums s_n;  LN_OUT: gamma of the next LayerNorm
     unsigned voffx[2];                                         // LN_OUT: offsets into the x16 copy
-    __amdgpu_buffer_rsrc_t rs_aux, rs_aux2;                    // LN_IN: rowstat;  LN_OUT: x16 and the partial statistics
+    __amdgpu_buffer_rsrc_t rs_aux, rs_aux2, rs_cm;             // LN_IN: rowstat;  LN_OUT: x16, the partial statistics and the row centres
     if constexpr (LN_IN) rs_aux = make_rsrc(p.rowstat + (size_t)m0w * 2, (unsigned)rows_valid * 8u);
     if constexpr (LN_OUT) {
         rs_aux = make_rsrc(p.x16 + (size_t)m0w * p.ldx16 * 2, (unsigned)rows_valid * (unsigned)p.ldx16 * 2u);
         // partial statistics, piece-major [N/64][M][2]: the descriptor spans all pieces from this sub-tile's first row; rows >= M of the last
         // tile row land in the next piece's first rows... so they are dropped by the row test below instead of the range check
         rs_aux2 = make_rsrc(p.stats_part + (size_t)m0w * 2, (unsigned)(((size_t)(p.N >> 6) - 1) * p.M * 8 + (size_t)rows_valid * 8));
+        // centres: a null rowmean gives a zero-size descriptor, whose loads return 0 (c = 0 without a branch)
+        rs_cm = make_rsrc(p.rowmean ? p.rowmean + m0w : (const float*)p.C, p.rowmean ? (unsigned)rows_valid * 4u : 0u);
     }
 #pragma unroll
     for (int jp = 0; jp < 2; ++jp) {
@@ -157,37 +166,30 @@ __device__ __forceinline__ void epilogue_w4(const KArgs& p, f32x16_t (&acc)[4][4
             bv[jp] = *(const f32x4_t*)(p.bias + min(col, p.N - 4));
         }
     }
-    // The epilogue's own loads are software-pipelined ONE STEP AHEAD (two register sets): the eight residual loads of piece p + 1 (RMW:
-    // a round trip to HBM) and the row statistics of row group i + 1 (LN_IN: L2) are issued before piece p is staged and finished, so a
-    // piece no longer starts with an exposed memory round trip.  (Issued-then-immediately-consumed they cost one round trip per piece:
-    // 8 x ~1.5 us of the ~22 us a 256 x 256 residual tile's epilogue took.)  Same arithmetic, same order: results are bit-identical.
-    u32x2_t rst[2][8];                                         // LN_IN: (mean, rstd) of the 8 rows, double-buffered over the row groups
-    u32x4_t old[2][8];                                         // RMW: the fp32 residual of a piece, double-buffered over the pieces
+    u32x2_t rst[8];                                            // LN_IN: (mean - centre, rstd) of the 8 rows
+    float cm[8];                                               // LN_OUT: centre of the 8 rows
+    float csh = 0.f;
+    if constexpr (LN_OUT) { if (p.rowmean && p.cshift) csh = *p.cshift; }
     float keep1 = 0.f, keep2 = 0.f;                            // LN_OUT: (sum, sum of squares) of the row this lane reports
-    auto load_rst = [&](int i, u32x2_t (&dst)[8]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) dst[r] = __builtin_amdgcn_raw_buffer_load_b64(rs_aux, (unsigned)(i * 32 + r * 4 + rrow) * 8u, 0, 0);
-    };
-    auto load_old = [&](int piece, u32x4_t (&dst)[8]) __attribute__((always_inline)) {
-        const int i = piece >> 1, jp = piece & 1;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) dst[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[jp] + (i * 32 + r * 4) * rowpitch, 0, 0);
-    };
-#ifdef PGV_LAB_EPI_NOPIPE
-    constexpr bool PIPE = false;                               // lab A/B build: loads issued right before their piece (the round-2 epilogue)
-#else
-    constexpr bool PIPE = true;
-#endif
-    if constexpr (LN_IN && PIPE) load_rst(0, rst[0]);
-    if constexpr (RMW && PIPE) load_old(0, old[0]);
 #pragma unroll
     for (int piece = 0; piece < 8; ++piece) {
         const int i = piece >> 1, jp = piece & 1;
         if constexpr (LN_IN) {
-            if (PIPE ? (jp == 0 && i < 3) : (jp == 0)) load_rst(PIPE ? i + 1 : i, rst[(PIPE ? i + 1 : i) & 1]);
+            if (jp == 0) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) rst[r] = __builtin_amdgcn_raw_buffer_load_b64(rs_aux, (unsigned)(i * 32 + r * 4 + rrow) * 8u, 0, 0);
+            }
         }
+        if constexpr (LN_OUT) {
+            if (jp == 0) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) cm[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_cm, (unsigned)(i * 32 + r * 4 + rrow) * 4u, 0, 0)) + csh;
+            }
+        }
+        u32x4_t old[8];
         if constexpr (RMW) {
-            if (PIPE ? (piece < 7) : true) load_old(PIPE ? piece + 1 : piece, old[(PIPE ? piece + 1 : piece) & 1]);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) old[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[jp] + (i * 32 + r * 4) * rowpitch, 0, 0);
         }
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
@@ -199,25 +201,17 @@ __device__ __forceinline__ void epilogue_w4(const KArgs& p, f32x16_t (&acc)[4][4
                 *(f32x4_t*)(stg + l31 * 256 + (((8 * jj + 2 * g + hi) ^ (l31 & 15)) << 4)) = v;
             }
         __builtin_amdgcn_wave_barrier();
-        // read side: all eight row reads of the piece are issued before the first is consumed (left to itself hipcc issues read, wait, finish,
-        // store, next read: eight exposed LDS round trips per piece -- the epilogue time did not depend on the bytes stored at all)
-        f32x4_t dv[8], uv[SWIGLU ? 8 : 1];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int row = r * 4 + rrow;
-            dv[r] = *(const f32x4_t*)(stg + row * 256 + ((rc ^ (row & 15)) << 4));
-            if constexpr (SWIGLU) uv[r] = *(const f32x4_t*)(stg + row * 256 + (((rc ^ 8) ^ (row & 15)) << 4));     // partner chunk: up (for rc < 8)
-        }
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
             const unsigned o = voff[jp] + (i * 32 + r * 4) * rowpitch;
-            f32x4_t d = dv[r];
+            f32x4_t d = *(const f32x4_t*)(stg + row * 256 + ((rc ^ (row & 15)) << 4));
             if constexpr (SWIGLU) {
-                const f32x4_t u = uv[r];
+                const f32x4_t u = *(const f32x4_t*)(stg + row * 256 + (((rc ^ 8) ^ (row & 15)) << 4));     // partner chunk: up (for rc < 8)
                 __builtin_amdgcn_raw_buffer_store_b64(pack4<T>(silu_f(d[0]) * u[0], silu_f(d[1]) * u[1], silu_f(d[2]) * u[2], silu_f(d[3]) * u[3]), rsrc, o, 0, 0);
             } else {
                 if constexpr (LN_IN) {
-                    const f32x2_t ms = __builtin_bit_cast(f32x2_t, rst[i & 1][r]);            // (mean, rstd)
+                    const f32x2_t ms = __builtin_bit_cast(f32x2_t, rst[r]);            // (mean, rstd)
                     const float a = ms[1], c = -ms[1] * ms[0];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) d[e] = a * d[e] + (c * sv[jp][e] + bv[jp][e]);       // rstd (acc - mean s_n) + b'_n
@@ -234,12 +228,13 @@ __device__ __forceinline__ void epilogue_w4(const KArgs& p, f32x16_t (&acc)[4][4
                     }
                 }
                 if constexpr (RMW) {
-                    const f32x4_t q = __builtin_bit_cast(f32x4_t, old[piece & 1][r]);
+                    const f32x4_t q = __builtin_bit_cast(f32x4_t, old[r]);
                     d[0] += q[0]; d[1] += q[1]; d[2] += q[2]; d[3] += q[3];
                 }
                 if constexpr (OUT32) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, d), rsrc, o, 0, 0);
                 else __builtin_amdgcn_raw_buffer_store_b64(pack4<T>(d[0], d[1], d[2], d[3]), rsrc, o, 0, 0);
                 if constexpr (LN_OUT) {
+                    d[0] -= cm[r]; d[1] -= cm[r]; d[2] -= cm[r]; d[3] -= cm[r];           // centred from here on (the fp32 residual above is not)
                     __builtin_amdgcn_raw_buffer_store_b64(pack4<T>(d[0] * sv[jp][0], d[1] * sv[jp][1], d[2] * sv[jp][2], d[3] * sv[jp][3]), rs_aux,
                                                           voffx[jp] + (unsigned)(i * 32 + r * 4) * (unsigned)p.ldx16 * 2u, 0, 0);
                     // the 16 lanes of a DPP row hold the 64 columns of this piece of one residual row: fold them (every lane gets the total);
@@ -339,12 +334,6 @@ __global__ __launch_bounds__(256, 1) void gemm_w4(KArgs p) {
     using First = std::true_type;
     using Later = std::false_type;
     rebaseA(blockIdx.x); rebaseW(blockIdx.x);
-#ifdef PGV_LAB
-    if (p.stagger_ticks > 0) {      // lab: de-phase the workgroups of an XCD by a start delay of (slot % 4) * stagger_ticks of the 100 MHz clock
-        const unsigned long long t0 = wall_clock64(), wait = (unsigned long long)((blockIdx.x >> 3) & 3) * (unsigned long long)p.stagger_ticks;
-        while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(8);
-    }
-#endif
 
     const int l31 = lane & 31, hi = lane >> 5;
     const int sw = (l31 >> 1) & 7;
@@ -385,17 +374,14 @@ __global__ __launch_bounds__(256, 1) void gemm_w4(KArgs p) {
                 if (t < 4) fa[set ^ 1][t] = *(const typename T::v8*)(ra + a_off + t * 4096 + koffs[rkk]);
                 else fw[set ^ 1][t - 4] = *(const typename T::v8*)(rw + w_off + (t - 4) * 4096 + koffs[rkk]);
             }
-            if constexpr (dmasel == 4) dma_one(S1{}, t);                         // the whole W tile in one group (one DMA per 2 MFMAs)
-            else if constexpr (dmasel >= 0) { if (t & 1) dma_one(Which{}, (dmasel & 1) * 4 + (t >> 1)); }
+            if constexpr (dmasel >= 0) { if (t & 1) dma_one(Which{}, (dmasel & 1) * 4 + (t >> 1)); }
         }
-        if constexpr (dmasel == 4) advance(S1{});
-        else if constexpr (dmasel >= 0 && (dmasel & 1)) advance(Which{});
+        if constexpr (dmasel >= 0 && (dmasel & 1)) advance(Which{});
     };
     using DmaA0 = std::integral_constant<int, 0>;
     using DmaA1 = std::integral_constant<int, 1>;
     using DmaW0 = std::integral_constant<int, 2>;
     using DmaW1 = std::integral_constant<int, 3>;
-    using DmaWall [[maybe_unused]] = std::integral_constant<int, 4>;
 
     // prologue: A0 W0 A1 and the first half of W1 (slots 0 1 2 3); the loop continues with W1's second half
 #pragma unroll
@@ -407,16 +393,9 @@ __global__ __launch_bounds__(256, 1) void gemm_w4(KArgs p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) dma_one(S0{}, j);
     advance(S0{});
-#ifdef PGV_LAB_W_EARLY
-#pragma unroll
-    for (int j = 0; j < 8; ++j) dma_one(S1{}, j);
-    advance(S1{});
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                  // K-step 0 landed (this wave's share)
-#else
 #pragma unroll
     for (int j = 0; j < 4; ++j) dma_one(S1{}, j);
     asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                  // K-step 0 landed (this wave's share)
-#endif
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int i = 0; i < 4; ++i) fa[0][i] = *(const typename T::v8*)(smem + a_off + i * 4096 + koffs[0]);
@@ -431,22 +410,15 @@ __global__ __launch_bounds__(256, 1) void gemm_w4(KArgs p) {
         const char* rw = smem + cw * SLOT;                                                                                  \
         int na = ca + 2; if (na >= 5) na -= 5;                                                                              \
         int nw = cw + 2; if (nw >= 5) nw -= 5;                                                                              \
-        group(FIRST{}, S0{}, ra, rw, 1, G0DMA{});                    /* + 2nd half of W(s+1) (slot of A(s-1))              */ \
+        group(FIRST{}, S0{}, ra, rw, 1, DmaW1{});                    /* + 2nd half of W(s+1) (slot of A(s-1))              */ \
         group(Later{}, S1{}, ra, rw, 2, DmaA0{});                    /* + A(s+2) into the slot W(s-1) left at the last barrier */ \
         group(Later{}, S0{}, ra, rw, 3, DmaA1{});                                                                           \
         if constexpr (ABL & 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                          \
         else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); /* step s+1 landed; only A(s+2) may still fly */   \
         if constexpr (!(ABL & 16)) __builtin_amdgcn_s_barrier();     /* ... for everyone, and step s is fully read */       \
-        group(Later{}, S1{}, smem + na * SLOT, smem + nw * SLOT, 0, G3DMA{}); /* + 1st half of W(s+2) into the slot of A(s) */ \
+        group(Later{}, S1{}, smem + na * SLOT, smem + nw * SLOT, 0, DmaW0{}); /* + 1st half of W(s+2) into the slot of A(s) */ \
         stg_slot = cw; ca = na; cw = nw;                                                                                    \
     }
-#ifdef PGV_LAB_W_EARLY
-    // lab variant: all of W(s+2) is issued in G3 of step s (right after the barrier that frees A(s)'s slot) instead of half there and half in
-    // G0 of step s+1: the tightest DMA deadline grows from 3 to 4 groups (is the K loop bound by the latency of that quarter of the bytes?)
-    using G0DMA = NoDma; using G3DMA = DmaWall;
-#else
-    using G0DMA = DmaW1; using G3DMA = DmaW0;
-#endif
     int stg_slot = 1;
     for (int vb = blockIdx.x; vb < total; vb += G) {
         PGV_W4_KSTEP(First)                                           // C = 0 form on the first k slice: no zeroing pass
@@ -485,7 +457,8 @@ int launch_w4(const KArgs& k, hipStream_t s, int num_cu) {
     static int abl = -1;
     if (abl < 0) { const char* e = getenv("PGV_GEMM_ABLATE"); abl = e ? atoi(e) : 0; }
     // Lab builds only (-DPGV_LAB): timing ablations (results are garbage), plain BIAS epilogue in bf16 only -- PGV_GEMM_ABLATE bits: 1 no DMA,
-    // 2 no fragment reads, 4 no MFMA, 8 no counted vmcnt wait, 16 no barrier, 32 no epilogue (scripts/microbench.py ablate).
+    // 2 no fragment reads, 4 no MFMA, 8 no counted vmcnt wait, 16 no barrier, 32 no epilogue (scripts/microbench.py ablate,
+    // scripts/lab/gemm_epi_decomp.py).
     // The release library has no switch that changes results.
     if constexpr (EPI == PGV_EPI_BIAS && T::id == PGV_BF16) {
         switch (abl) {
@@ -542,10 +515,7 @@ int pgv_launch_gemm(pgv_ctx* ctx, int dtype, const GemmArgs& a, hipStream_t s) {
     k.lda = a.lda; k.ldw = a.ldw; k.ldc = a.ldc; k.M = a.M; k.N = a.N; k.K = a.K;
     k.ntm = 0; k.ntn = 0;
     k.wblk = a.w_blocked ? 1 : 0;
-    k.rowstat = a.rowstat; k.colsum = a.colsum; k.gnext = a.gnext; k.x16 = (char*)a.x16; k.ldx16 = a.ldx16; k.stats_part = a.stats_part;
-#ifdef PGV_LAB
-    { static int st = -1; if (st < 0) { const char* e = getenv("PGV_GEMM_STAGGER"); st = e ? atoi(e) : 0; } k.stagger_ticks = (a.epi == EPI_BIAS_RESID_LNOUT) ? st : 0; }
-#endif
+    k.rowstat = a.rowstat; k.colsum = a.colsum; k.gnext = a.gnext; k.x16 = (char*)a.x16; k.ldx16 = a.ldx16; k.stats_part = a.stats_part; k.rowmean = a.rowmean; k.cshift = a.cshift;
     PGV_CHECK(!a.w_blocked || a.N % 16 == 0, "gemm: blocked weights need N %% 16 == 0");
     if (k.bias == nullptr) {        // the branch-free epilogue always reads a bias vector
         PGV_CHECK(a.N <= PGV_ZERO_BIAS_LEN, "gemm: N=%d exceeds the zero-bias vector", a.N);

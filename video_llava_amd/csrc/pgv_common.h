@@ -166,9 +166,11 @@ struct GemmArgs {
     int M, N, K;
     int epi;
     bool w_blocked = false;       // W in the fragment-blocked layout (weights.h) -- the decoder's packed weights
-    // folded LayerNorm (gemm.hip, EPI_LN_*): consumer side rowstat [M][2] + colsum [N]; producer side gnext [N], x16 [M][ldx16], stats_part [M][N/64][2]
+    // folded LayerNorm (gemm.hip, EPI_LN_*): consumer side rowstat [M][2] + colsum [N]; producer side gnext [N], x16 [M][ldx16], stats_part [N/64][M][2], rowmean [M]
     const float* rowstat = nullptr; const float* colsum = nullptr;
     const float* gnext = nullptr; void* x16 = nullptr; int ldx16 = 0; float* stats_part = nullptr;
+    const float* rowmean = nullptr;      // producer: per-row mean before the sublayer (null: centre 0)
+    const float* cshift = nullptr;       // producer: device scalar mean(bias), added to rowmean to form the centre
 };
 enum { PGV_EPI_LN_BIAS = 8, PGV_EPI_LN_BIAS_QGELU = 9, PGV_EPI_BIAS_RESID_LNOUT = 10 };     // internal epilogues (gemm.hip)
 int pgv_launch_gemm(pgv_ctx* ctx, int dtype, const GemmArgs& a, hipStream_t s);

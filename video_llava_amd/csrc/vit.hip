@@ -10,8 +10,9 @@
 
 int pgv_launch_layernorm(int dtype, const float* x, const float* g, const float* b, float eps, void* y, int rows, int cols, hipStream_t s);
 int pgv_launch_embed_ln(int dtype, const float* pe, const float* cls, const float* pos, const float* g, const float* b, float eps, float* out,
-                        int rows, int tokens, int cols, const float* gnext, void* x16, float* rowstat, hipStream_t s);
-int pgv_launch_ln_stats(const float* part, float* rowstat, int rows, int np, int cols, float eps, hipStream_t s);
+                        int rows, int tokens, int cols, const float* gnext, void* x16, float* rowstat, float* rowmean, hipStream_t s);
+int pgv_launch_ln_stats(const float* part, float* rowstat, float* rowmean, const float* cshift, int rows, int np, int cols, float eps, hipStream_t s);
+int pgv_launch_vec_mean(const float* x, int n, float* out, hipStream_t s);
 int pgv_launch_ln_fold(int dtype, const void* W, const float* bias, const float* gamma, const float* beta, float* colsum, float* bias2, int N, int K, hipStream_t s);
 int pgv_launch_cast(int dtype, const float* x, void* y, size_t n, hipStream_t s);
 int pgv_launch_im2col(const void* pix, void* a0, int T, int S, int g, int p, int Kp, hipStream_t s);
@@ -24,6 +25,7 @@ struct VitLayer {
     // folded LayerNorm (gemm.hip EPI_LN_*), derived from the loaded tensors before the first forward: column sums sum_k gamma_k W[n,k]
     // and biases b + W beta of the two GEMMs that consume a LayerNorm (qkv after layer_norm1, fc1 after layer_norm2)
     float *s_qkv, *b2_qkv, *s_fc1, *b2_fc1;
+    float *m_bo, *m_b2;            // device scalars: mean of the out_proj / fc2 bias (centre shift of the folded-LayerNorm producers)
 };
 
 struct pgv_vit {
@@ -59,13 +61,14 @@ extern "C" int pgv_vit_create(pgv_ctx* ctx, const pgv_vit_config* cfg, int dtype
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += pgv_align(bytes); return o; };
     const size_t o_patch = take(C * v->Kp * 2), o_cls = take(C * 4), o_pos = take((size_t)v->tokens * C * 4), o_pg = take(C * 4), o_pb = take(C * 4), o_ones = take(C * 4);
-    struct LO { size_t ln1g, ln1b, ln2g, ln2b, wqkv, wo, w1, w2, bqkv, bo, b1, b2, sqkv, b2qkv, sfc1, b2fc1; };
+    struct LO { size_t ln1g, ln1b, ln2g, ln2b, wqkv, wo, w1, w2, bqkv, bo, b1, b2, sqkv, b2qkv, sfc1, b2fc1, mbo, mb2; };
     std::vector<LO> lo(L);
     for (size_t i = 0; i < L; ++i) {
         lo[i].ln1g = take(C * 4); lo[i].ln1b = take(C * 4); lo[i].ln2g = take(C * 4); lo[i].ln2b = take(C * 4);
         lo[i].wqkv = take(3 * C * C * 2); lo[i].wo = take(C * C * 2); lo[i].w1 = take(I * C * 2); lo[i].w2 = take(C * I * 2);
         lo[i].bqkv = take(3 * C * 4); lo[i].bo = take(C * 4); lo[i].b1 = take(I * 4); lo[i].b2 = take(C * 4);
         lo[i].sqkv = take(3 * C * 4); lo[i].b2qkv = take(3 * C * 4); lo[i].sfc1 = take(I * 4); lo[i].b2fc1 = take(I * 4);
+        lo[i].mbo = take(4); lo[i].mb2 = take(4);
     }
     hipError_t e = hipMalloc((void**)&v->blob, off);
     if (e != hipSuccess) { delete v; pgv_set_error("pgv_vit_create: hipMalloc(%zu MiB): %s", off >> 20, hipGetErrorString(e)); return PGV_ENOMEM; }
@@ -84,6 +87,7 @@ extern "C" int pgv_vit_create(pgv_ctx* ctx, const pgv_vit_config* cfg, int dtype
         l.wqkv = b + lo[i].wqkv; l.wo = b + lo[i].wo; l.w1 = b + lo[i].w1; l.w2 = b + lo[i].w2;
         l.bqkv = (float*)(b + lo[i].bqkv); l.bo = (float*)(b + lo[i].bo); l.b1 = (float*)(b + lo[i].b1); l.b2 = (float*)(b + lo[i].b2);
         l.s_qkv = (float*)(b + lo[i].sqkv); l.b2_qkv = (float*)(b + lo[i].b2qkv); l.s_fc1 = (float*)(b + lo[i].sfc1); l.b2_fc1 = (float*)(b + lo[i].b2fc1);
+        l.m_bo = (float*)(b + lo[i].mbo); l.m_b2 = (float*)(b + lo[i].mb2);
     }
     v->expected = 5 + 16 * (int)L;   // post_layernorm is accepted but not needed for hidden_states
     *out = v;
@@ -172,6 +176,8 @@ extern "C" int pgv_vit_forward(pgv_ctx* ctx, pgv_vit* v, const void* d_pixels, i
         for (auto& l : v->layers) {
             PGV_TRY(pgv_launch_ln_fold(v->dtype, l.wqkv, l.bqkv, l.ln1_g, l.ln1_b, l.s_qkv, l.b2_qkv, 3 * C, C, s));
             PGV_TRY(pgv_launch_ln_fold(v->dtype, l.w1, l.b1, l.ln2_g, l.ln2_b, l.s_fc1, l.b2_fc1, I, C, s));
+            PGV_TRY(pgv_launch_vec_mean(l.bo, C, l.m_bo, s));
+            PGV_TRY(pgv_launch_vec_mean(l.b2, C, l.m_b2, s));
         }
         v->folded = true;
     }
@@ -189,9 +195,9 @@ extern "C" int pgv_vit_forward(pgv_ctx* ctx, pgv_vit* v, const void* d_pixels, i
     const int NP = C / 64;             // 64-column pieces of a residual row (partial statistics of the folded LayerNorm)
     const size_t b_resid = pgv_align(Mmax * C * 4), b_xn = pgv_align(Mmax * C * 2), b_qkv = pgv_align(Mmax * 3 * C * 2), b_ao = pgv_align(Mmax * C * 2),
                  b_h = pgv_align(Mmax * I * 2 > (size_t)Tc_max * P * ((size_t)v->Kp * 2 + C * 4) + 512 ? Mmax * I * 2 : (size_t)Tc_max * P * ((size_t)v->Kp * 2 + C * 4) + 512),
-                 b_part = pgv_align(Mmax * NP * 8), b_stat = pgv_align(Mmax * 8);
-    PGV_TRY(pgv_ws_reserve(ctx, (size_t)lanes * (b_resid + b_xn + b_qkv + b_ao + b_h + b_part + b_stat), s));
-    struct Lane { hipStream_t s; float* resid; char *xn, *qkv, *ao, *hbuf; float *part, *rowstat; int t0, T, done; } L[2];
+                 b_part = pgv_align(Mmax * NP * 8), b_stat = pgv_align(Mmax * 8), b_mean = pgv_align(Mmax * 4);
+    PGV_TRY(pgv_ws_reserve(ctx, (size_t)lanes * (b_resid + b_xn + b_qkv + b_ao + b_h + b_part + b_stat + b_mean), s));
+    struct Lane { hipStream_t s; float* resid; char *xn, *qkv, *ao, *hbuf; float *part, *rowstat, *rowmean; int t0, T, done; } L[2];
     for (int k = 0; k < lanes; ++k) {
         L[k].resid = (float*)pgv_ws_alloc(ctx, b_resid);
         L[k].xn = (char*)pgv_ws_alloc(ctx, b_xn);
@@ -200,7 +206,8 @@ extern "C" int pgv_vit_forward(pgv_ctx* ctx, pgv_vit* v, const void* d_pixels, i
         L[k].hbuf = (char*)pgv_ws_alloc(ctx, b_h);
         L[k].part = (float*)pgv_ws_alloc(ctx, b_part);
         L[k].rowstat = (float*)pgv_ws_alloc(ctx, b_stat);
-        PGV_CHECK(L[k].resid && L[k].xn && L[k].qkv && L[k].ao && L[k].hbuf && L[k].part && L[k].rowstat, "pgv_vit_forward: workspace exhausted");
+        L[k].rowmean = (float*)pgv_ws_alloc(ctx, b_mean);
+        PGV_CHECK(L[k].resid && L[k].xn && L[k].qkv && L[k].ao && L[k].hbuf && L[k].part && L[k].rowstat && L[k].rowmean, "pgv_vit_forward: workspace exhausted");
         L[k].s = s; L[k].t0 = lane_t0[k]; L[k].T = lane_T[k]; L[k].done = 0;
     }
     if (lanes == 2) {
@@ -224,13 +231,13 @@ extern "C" int pgv_vit_forward(pgv_ctx* ctx, pgv_vit* v, const void* d_pixels, i
         g.A = a0; g.lda = v->Kp; g.W = v->patch_w; g.ldw = v->Kp; g.bias = nullptr; g.C = pe; g.ldc = C; g.M = Tc * P; g.N = C; g.K = v->Kp; g.epi = PGV_EPI_F32;
         PGV_TRY(pgv_launch_gemm(ctx, v->dtype, g, ln.s));
         const bool f0 = fold && n_layers > 0;
-        PGV_TRY(pgv_launch_embed_ln(v->dtype, pe, v->cls, v->pos, v->pre_g, v->pre_b, v->cfg.eps, ln.resid, M, N, C, f0 ? v->layers[0].ln1_g : nullptr, ln.xn, ln.rowstat, ln.s));
+        PGV_TRY(pgv_launch_embed_ln(v->dtype, pe, v->cls, v->pos, v->pre_g, v->pre_b, v->cfg.eps, ln.resid, M, N, C, f0 ? v->layers[0].ln1_g : nullptr, ln.xn, ln.rowstat, ln.rowmean, ln.s));
         return PGV_OK;
     };
     auto layer = [&](Lane& ln, int t0, int Tc, int li) -> int {
         const int M = Tc * N;
         const VitLayer& l = v->layers[li];
-        float* resid = ln.resid; char *xn = ln.xn, *qkv = ln.qkv, *ao = ln.ao, *hbuf = ln.hbuf; float *part = ln.part, *rowstat = ln.rowstat;
+        float* resid = ln.resid; char *xn = ln.xn, *qkv = ln.qkv, *ao = ln.ao, *hbuf = ln.hbuf; float *part = ln.part, *rowstat = ln.rowstat, *rowmean = ln.rowmean;
         hipStream_t s = ln.s;
         GemmArgs g{};
         if (fold) {
@@ -240,17 +247,17 @@ extern "C" int pgv_vit_forward(pgv_ctx* ctx, pgv_vit* v, const void* d_pixels, i
             PGV_TRY(pgv_launch_gemm(ctx, v->dtype, g, s));
             PGV_TRY(pgv_launch_vit_attn(ctx, v->dtype, qkv, 3 * C, ao, C, Tc, N, C, v->cfg.heads, s));
             g = GemmArgs{}; g.A = ao; g.lda = C; g.W = l.wo; g.ldw = C; g.bias = l.bo; g.C = resid; g.ldc = C; g.M = M; g.N = C; g.K = C;
-            g.epi = PGV_EPI_BIAS_RESID_LNOUT; g.gnext = l.ln2_g; g.x16 = xn; g.ldx16 = C; g.stats_part = part;
+            g.epi = PGV_EPI_BIAS_RESID_LNOUT; g.gnext = l.ln2_g; g.x16 = xn; g.ldx16 = C; g.stats_part = part; g.rowmean = rowmean; g.cshift = l.m_bo;
             PGV_TRY(pgv_launch_gemm(ctx, v->dtype, g, s));
-            PGV_TRY(pgv_launch_ln_stats(part, rowstat, M, NP, C, v->cfg.eps, s));
+            PGV_TRY(pgv_launch_ln_stats(part, rowstat, rowmean, l.m_bo, M, NP, C, v->cfg.eps, s));
             g = GemmArgs{}; g.A = xn; g.lda = C; g.W = l.w1; g.ldw = C; g.bias = l.b2_fc1; g.C = hbuf; g.ldc = I; g.M = M; g.N = I; g.K = C;
             g.epi = PGV_EPI_LN_BIAS_QGELU; g.rowstat = rowstat; g.colsum = l.s_fc1;
             PGV_TRY(pgv_launch_gemm(ctx, v->dtype, g, s));
             g = GemmArgs{}; g.A = hbuf; g.lda = I; g.W = l.w2; g.ldw = I; g.bias = l.b2; g.C = resid; g.ldc = C; g.M = M; g.N = C; g.K = I;
             if (li + 1 < n_layers) {
-                g.epi = PGV_EPI_BIAS_RESID_LNOUT; g.gnext = v->layers[li + 1].ln1_g; g.x16 = xn; g.ldx16 = C; g.stats_part = part;
+                g.epi = PGV_EPI_BIAS_RESID_LNOUT; g.gnext = v->layers[li + 1].ln1_g; g.x16 = xn; g.ldx16 = C; g.stats_part = part; g.rowmean = rowmean; g.cshift = l.m_b2;
                 PGV_TRY(pgv_launch_gemm(ctx, v->dtype, g, s));
-                PGV_TRY(pgv_launch_ln_stats(part, rowstat, M, NP, C, v->cfg.eps, s));
+                PGV_TRY(pgv_launch_ln_stats(part, rowstat, rowmean, l.m_b2, M, NP, C, v->cfg.eps, s));
             } else {
                 // the last executed layer feeds no LayerNorm: its "operand copy" with gamma = 1 is round16(resid) -- the hidden state itself,
                 // written straight into the caller's buffer (no cast pass over the fp32 residual); the statistics are discarded
