@@ -350,3 +350,40 @@ def test_native_frames_route_through_ingest(ctx, tmp_path):
     a = frames_to_pixels(native, None, tower)
     b = frames_to_pixels(host, None, tower)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("shift,outliers", [(0.0, False), (1.0, False), (5.0, False), (20.0, False), (0.0, True), (5.0, True)])
+def test_folded_layernorm_mean_dominated_rows(ctx, shift, outliers):
+    """The LayerNorm folded into the CLIP GEMMs (csrc/gemm.hip EPI_LN_*) rounds its operand to 16 bits BEFORE the normalisation.  In the
+    centred form the rounded operand is (x - c) gamma with c tracking the row mean, so rows whose mean dominates their spread (|mu| / sigma =
+    `shift`) or that carry a few massive channels (as released ViT-L checkpoints do) must come out as accurate as the zero-mean rows of a
+    random-init tower.  Construction: layer 0's out_proj bias moves every residual row by +shift (and +80 on four channels with
+    `outliers`), the last layer's fc2 bias moves it back, so 11 of the 12 LayerNorms of a 6-layer tower see the shifted rows while the
+    16-bit OUTPUT keeps its usual magnitude (otherwise the output rounding itself would swamp the comparison).  fp16, <= 1e-3 normwise vs
+    the fp32 oracle, and no worse than 1.5 x the unshifted tower."""
+    cfg = synth.ClipCfg(hidden=1024, inter=512, layers=6, heads=16, image=56, patch=14)
+    base = synth.make_clip_weights(cfg, seed=5)
+    frames = synth.make_frames(7, cfg.image, seed=6)
+    px = ovis.clip_preprocess(frames)
+
+    def run(sh, outl):
+        w = {k: v.copy() for k, v in base.items()}
+        delta = np.full(1024, sh, np.float32)
+        if outl:
+            delta[[7, 300, 301, 900]] += 80.0
+        w["vision_model.encoder.layers.0.self_attn.out_proj.bias"] = w["vision_model.encoder.layers.0.self_attn.out_proj.bias"] + delta
+        w[f"vision_model.encoder.layers.{cfg.layers - 1}.mlp.fc2.bias"] = w[f"vision_model.encoder.layers.{cfg.layers - 1}.mlp.fc2.bias"] - delta
+        tower = _tower(cfg, w, torch.float16)
+        got = tower(px.half().to(DEV), output_hidden_states=True).hidden_states[cfg.layers]
+        ref = ovis.clip_hidden_states(px, w, cfg)[cfg.layers]
+        mid = ovis.clip_hidden_states(px, w, cfg, upto=2)[2]
+        ratio = float((mid.mean(-1).abs() / mid.std(-1)).median())
+        return rel(got, ref), ratio
+
+    e0, r0 = run(0.0, False)
+    e, r = run(shift, outliers)
+    print(f"folded LayerNorm, shift {shift} outliers {outliers}: |mu|/sigma of the rows the LayerNorms see = {r:.2f} (unshifted {r0:.2f}); "
+          f"tower error {e:.3e} (unshifted {e0:.3e})")
+    if shift > 0 and not outliers:
+        assert r > 0.5 * shift
+    assert e < 1e-3 and e < 1.5 * e0 + 1e-5

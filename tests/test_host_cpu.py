@@ -546,3 +546,52 @@ def test_run_sharded_prefetches_one_group_ahead():
     assert all(e[2] != main for e in events if e[0] == "prep_start") and all(e[2] == main for e in events if e[0] == "infer_start")
     # never more than one group ahead
     assert names.index(("prep_start", (4, 5))) > names.index(("infer_start", (0, 1)))
+
+
+def test_first_stop_length_survives_a_non_monotone_decoder():
+    """`keyword in decode(tokens[:n])` need not be monotone (byte-fallback pieces decode to U+FFFD until complete).  The search
+    result is verified and a linear scan takes over: the answer must equal the reference's per-token loop for such a decoder too."""
+    from video_llava_amd.model.utils import first_stop_length
+
+    class Tok:
+        """Token 9 followed by token 8 decodes to 'ab'; a trailing lone 9 decodes to U+FFFD (an incomplete byte-fallback piece); 5 erases the
+        previous character only when it directly follows 8 at the END of the sequence (a decoder that strips a trailing piece)."""
+        def __call__(self, s):
+            class R: pass
+            r = R(); r.input_ids = [1, 2, 3]; return r
+        def batch_decode(self, rows, skip_special_tokens=True):
+            out = []
+            for row in rows:
+                t = ""
+                for i, x in enumerate(row):
+                    if x == 9:
+                        t += "a" if i + 1 < len(row) else "�"
+                    elif x == 8:
+                        t += "b"
+                    elif x == 5:
+                        t = t[:-1] if i + 1 == len(row) else t + "y"
+                    else:
+                        t += "x"
+                out.append(t)
+            return out
+
+    def per_token(toks, kw):                       # the reference's loop: stop at the first n >= 2 whose decoded prefix holds the keyword
+        tk = Tok()
+        return next((n for n in range(2, len(toks) + 1) if kw in tk.batch_decode([toks[:n]])[0]), None)
+
+    for toks in ([7, 9, 8, 7, 7], [7, 7, 9, 8, 5, 7, 7, 7], [7, 9, 8, 5], [7, 7, 7], [7, 9], [9, 8], [7, 7, 7, 9, 8, 9], [9, 8, 9, 8, 9]):
+        assert first_stop_length(toks, Tok(), ["ab"]) == per_token(toks, "ab"), toks
+
+
+def test_device_resize_upload_is_bounded(tmp_path):
+    """the native-resolution upload of the runners (`device_resize=True`) is capped; above the cap the frames are resized on the host."""
+    from video_llava_amd import feature_extraction as fx
+    small = np.zeros((4, 48, 64, 3), np.uint8); np.save(tmp_path / "s.npy", small)
+    assert isinstance(fx.load_video(str(tmp_path / "s.npy"), shape=(14, 14), device_resize=True), fx.NativeFrames)
+    old = fx.DEVICE_RESIZE_MAX_BYTES
+    fx.DEVICE_RESIZE_MAX_BYTES = small.nbytes - 1
+    try:
+        out = fx.load_video(str(tmp_path / "s.npy"), shape=(14, 14), device_resize=True)
+        assert isinstance(out, np.ndarray) and out.shape == (4, 14, 14, 3)
+    finally:
+        fx.DEVICE_RESIZE_MAX_BYTES = old

@@ -47,9 +47,9 @@ extern "C" void pgv_ctx_destroy(pgv_ctx* ctx) {
     if (ctx->zero_bias) (void)hipFree(ctx->zero_bias);
     if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
     if (ctx->ws_event) (void)hipEventDestroy(ctx->ws_event);
-    if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
+    for (auto st : ctx->aux_stream) if (st) (void)hipStreamDestroy(st);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    for (auto ev : ctx->ev_join) if (ev) (void)hipEventDestroy(ev);
     for (auto& f : ctx->fam)
         for (auto e : f.ev) (void)hipEventDestroy(e);
     delete ctx;

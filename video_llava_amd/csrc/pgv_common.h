@@ -60,8 +60,8 @@ struct pgv_ctx {
     hipStream_t ws_stream = nullptr;    // stream of the last call that carved the arena: compared by value only, never used after that call
     bool ws_stream_valid = false;
     hipEvent_t ws_event = nullptr;      // recorded on the user's stream at the end of every arena-using call (pgv_ws_release)
-    hipStream_t aux_stream = nullptr;   // second lane of the two-lane ViT pass (vit.hip): forked from / joined into the caller's stream by events
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t aux_stream[3] = {nullptr, nullptr, nullptr};   // further lanes of the multi-lane ViT pass (vit.hip): forked from / joined into the caller's stream by events
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     float* zero_bias = nullptr;         // PGV_ZERO_BIAS_LEN zeros: stands in for a null bias so the persistent GEMM epilogue is branch-free
 };
 

@@ -158,10 +158,11 @@ static bool ln_fold_enabled() {
     return v == 1;
 }
 
-static bool vit_lanes_enabled() {
+constexpr int MAX_LANES = 4;
+static int vit_lanes() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("PGV_VIT_LANES"); v = (e && e[0] == '1') ? 0 : 1; }     // PGV_VIT_LANES=1: single lane (A/B switch, identical results)
-    return v == 1;
+    if (v < 0) { const char* e = getenv("PGV_VIT_LANES"); v = e ? atoi(e) : 2; if (v < 1) v = 1; if (v > MAX_LANES) v = MAX_LANES; }   // A/B switch: results are identical for any value
+    return v;
 }
 
 extern "C" int pgv_vit_forward(pgv_ctx* ctx, pgv_vit* v, const void* d_pixels, int T, int n_layers, void* d_hidden, void* stream) {
@@ -183,21 +184,25 @@ extern "C" int pgv_vit_forward(pgv_ctx* ctx, pgv_vit* v, const void* d_pixels, i
     }
     // ---- lanes ----------------------------------------------------------------------------------------------------------------------
     // A pass is a chain of ~160 dependent launches, each a persistent grid whose last round fills only part of the chip (N = 1024 GEMMs at
-    // 800 frames: 3216 tiles = 12.56 rounds of 256 CUs; one 100-frame clip: 404 tiles = 1.58 rounds).  With TWO lanes -- the frames split in
-    // halves, each half its own chain on its own stream and its own workspace -- the idle CUs of one lane's tail run the head of the other
+    // 800 frames: 3216 tiles = 12.56 rounds of 256 CUs; one 100-frame clip: 404 tiles = 1.58 rounds).  With several lanes (two by default) -- the frames split in
+    // equal parts, each part its own chain on its own stream and its own workspace -- the idle CUs of one lane's tail run the head of the other
     // lane's next kernel.  Per-frame results do not depend on how frames are batched (bitwise; tests/test_gpu_vision.py), so the split is
     // invisible in the output.  The second stream is forked from and joined back into the caller's stream with events.
-    const int lanes = (vit_lanes_enabled() && !ctx->prof && T >= 16) ? 2 : 1;     // per-launch profiling wants kernels alone on the chip
-    int lane_t0[2] = {0, 0}, lane_T[2] = {T, 0};
-    if (lanes == 2) { lane_T[0] = (T + 1) / 2; lane_t0[1] = lane_T[0]; lane_T[1] = T - lane_T[0]; }
-    const int Tc_max = lane_T[0] < v->max_chunk_frames ? lane_T[0] : v->max_chunk_frames;
+    const int lanes = (!ctx->prof && T >= 8 * vit_lanes()) ? vit_lanes() : 1;     // per-launch profiling wants kernels alone on the chip
+    int lane_t0[MAX_LANES] = {0}, lane_T[MAX_LANES] = {T};
+    for (int k = 0, at = 0; k < lanes; ++k) { lane_t0[k] = at; lane_T[k] = (T - at + (lanes - k) - 1) / (lanes - k); at += lane_T[k]; }
+    int chunk_frames = v->max_chunk_frames;
+#ifdef PGV_LAB
+    { static int c = -1; if (c < 0) { const char* e = getenv("PGV_VIT_CHUNK"); c = e ? atoi(e) : 0; } if (c > 0) chunk_frames = c; }   // lab: frames per lane and pass
+#endif
+    const int Tc_max = lane_T[0] < chunk_frames ? lane_T[0] : chunk_frames;
     const size_t Mmax = (size_t)Tc_max * N;
     const int NP = C / 64;             // 64-column pieces of a residual row (partial statistics of the folded LayerNorm)
     const size_t b_resid = pgv_align(Mmax * C * 4), b_xn = pgv_align(Mmax * C * 2), b_qkv = pgv_align(Mmax * 3 * C * 2), b_ao = pgv_align(Mmax * C * 2),
                  b_h = pgv_align(Mmax * I * 2 > (size_t)Tc_max * P * ((size_t)v->Kp * 2 + C * 4) + 512 ? Mmax * I * 2 : (size_t)Tc_max * P * ((size_t)v->Kp * 2 + C * 4) + 512),
                  b_part = pgv_align(Mmax * NP * 8), b_stat = pgv_align(Mmax * 8), b_mean = pgv_align(Mmax * 4);
     PGV_TRY(pgv_ws_reserve(ctx, (size_t)lanes * (b_resid + b_xn + b_qkv + b_ao + b_h + b_part + b_stat + b_mean), s));
-    struct Lane { hipStream_t s; float* resid; char *xn, *qkv, *ao, *hbuf; float *part, *rowstat, *rowmean; int t0, T, done; } L[2];
+    struct Lane { hipStream_t s; float* resid; char *xn, *qkv, *ao, *hbuf; float *part, *rowstat, *rowmean; int t0, T, done; } L[MAX_LANES];
     for (int k = 0; k < lanes; ++k) {
         L[k].resid = (float*)pgv_ws_alloc(ctx, b_resid);
         L[k].xn = (char*)pgv_ws_alloc(ctx, b_xn);
@@ -210,13 +215,15 @@ extern "C" int pgv_vit_forward(pgv_ctx* ctx, pgv_vit* v, const void* d_pixels, i
         PGV_CHECK(L[k].resid && L[k].xn && L[k].qkv && L[k].ao && L[k].hbuf && L[k].part && L[k].rowstat && L[k].rowmean, "pgv_vit_forward: workspace exhausted");
         L[k].s = s; L[k].t0 = lane_t0[k]; L[k].T = lane_T[k]; L[k].done = 0;
     }
-    if (lanes == 2) {
-        if (!ctx->aux_stream) PGV_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+    if (lanes > 1) {
         if (!ctx->ev_fork) PGV_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-        if (!ctx->ev_join) PGV_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
         PGV_HIP(hipEventRecord(ctx->ev_fork, s));
-        PGV_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
-        L[1].s = ctx->aux_stream;
+        for (int k = 1; k < lanes; ++k) {
+            if (!ctx->aux_stream[k - 1]) PGV_HIP(hipStreamCreateWithFlags(&ctx->aux_stream[k - 1], hipStreamNonBlocking));
+            if (!ctx->ev_join[k - 1]) PGV_HIP(hipEventCreateWithFlags(&ctx->ev_join[k - 1], hipEventDisableTiming));
+            PGV_HIP(hipStreamWaitEvent(ctx->aux_stream[k - 1], ctx->ev_fork, 0));
+            L[k].s = ctx->aux_stream[k - 1];
+        }
     }
 
     // one chunk (<= Tc_max frames) of a lane, phase by phase so that the two lanes' launches are enqueued alternately
@@ -283,8 +290,9 @@ extern "C" int pgv_vit_forward(pgv_ctx* ctx, pgv_vit* v, const void* d_pixels, i
         if (!(fold && n_layers > 0)) PGV_TRY(pgv_launch_cast(v->dtype, ln.resid, (char*)d_hidden + (size_t)t0 * N * C * 2, (size_t)Tc * N * C, ln.s));
         return PGV_OK;
     };
-    while (L[0].done < L[0].T || (lanes == 2 && L[1].done < L[1].T)) {
-        int ct0[2], cT[2];
+    auto pending = [&]() { for (int k = 0; k < lanes; ++k) if (L[k].done < L[k].T) return true; return false; };
+    while (pending()) {
+        int ct0[MAX_LANES], cT[MAX_LANES];
         for (int k = 0; k < lanes; ++k) {
             ct0[k] = L[k].t0 + L[k].done;
             cT[k] = (L[k].T - L[k].done) < Tc_max ? (L[k].T - L[k].done) : Tc_max;
@@ -294,9 +302,9 @@ extern "C" int pgv_vit_forward(pgv_ctx* ctx, pgv_vit* v, const void* d_pixels, i
             for (int k = 0; k < lanes; ++k) if (cT[k] > 0) PGV_TRY(layer(L[k], ct0[k], cT[k], li));
         for (int k = 0; k < lanes; ++k) if (cT[k] > 0) { PGV_TRY(tail(L[k], ct0[k], cT[k])); L[k].done += cT[k]; }
     }
-    if (lanes == 2) {
-        PGV_HIP(hipEventRecord(ctx->ev_join, ctx->aux_stream));
-        PGV_HIP(hipStreamWaitEvent(s, ctx->ev_join, 0));
+    for (int k = 1; k < lanes; ++k) {
+        PGV_HIP(hipEventRecord(ctx->ev_join[k - 1], ctx->aux_stream[k - 1]));
+        PGV_HIP(hipStreamWaitEvent(s, ctx->ev_join[k - 1], 0));
     }
     PGV_TRY(pgv_ws_release(ctx, s));
     PGV_HIP(hipGetLastError());

@@ -117,6 +117,9 @@ def sample_frames(vis_path, num_frm=100) -> np.ndarray:
     return vr.get_batch(get_seq_frames(total, k)).asnumpy()
 
 
+DEVICE_RESIZE_MAX_BYTES = 256 << 20     # native-resolution upload cap per clip (100 frames of 720p = 276 MB is already above; 480p = 92 MB)
+
+
 def load_video(vis_path, num_frm=100, shape=(224, 224), device_resize=False):
     """Up to `num_frm` uniformly sampled frames as a uint8 array [k, h, w, 3]: nearest-neighbour resize to `shape` without aspect
     preservation, exactly the arithmetic of the reference (:13-32; F.interpolate default mode on the float tensor, cast back to
@@ -124,8 +127,10 @@ def load_video(vis_path, num_frm=100, shape=(224, 224), device_resize=False):
     device_resize=True returns the frames un-resized as `NativeFrames`: inference.frames_to_pixels then resizes and normalises them
     in one HIP pass (pgv_ingest_u8)."""
     arr = sample_frames(vis_path, num_frm)
-    if device_resize:
+    if device_resize and arr.nbytes <= DEVICE_RESIZE_MAX_BYTES:
         return NativeFrames(arr, shape)
+    # large sources (100 frames of 1080p = 620 MB, 4K = 2.5 GB) are resized on the host: the upload then is the 15 MB of crop-sized frames
+    # instead of a transient device allocation that scales with the source resolution (next to a 13B model + KV cache that can be an OOM)
     return resize_nearest(arr, shape)
 
 

@@ -25,11 +25,16 @@ class KeywordsStoppingCriteria:
         return any(k in text for k in self.keywords)
 
 
+LINEAR_SCAN_MAX = 192      # answers up to this many tokens are scanned prefix by prefix like the reference (O(n^2) decodes, negligible at this size)
+
+
 def first_stop_length(new_tokens, tokenizer, keywords):
     """Number of generated tokens a per-token loop with `KeywordsStoppingCriteria(keywords, ...)` keeps, or None when it never fires.
     The criterion's first call (one generated token) only records the start; from the second token on it fires when the last id is a
     single-id keyword or the decoded tail contains a keyword -- so this is the smallest n >= 2 with either property.  `keyword in
-    decode(tokens[:n])` is monotone in n for text keywords, hence a binary search instead of the reference's decode-per-token."""
+    decode(tokens[:n])` is monotone in n for the ASCII stop strings of the conversation templates, hence a binary search instead of the
+    reference's decode-per-token; monotonicity can fail for byte-fallback pieces (a prefix decodes to U+FFFD until the piece completes) or
+    decoders that merge / strip across tokens, so the result is verified (`has(n - 1)` must be False) and a linear scan takes over if not."""
     ids = [tokenizer(k).input_ids for k in keywords]
     keyword_ids = {i[0] for i in ids if isinstance(i, list) and len(i) == 1}
     toks = [int(t) for t in new_tokens]
@@ -40,7 +45,10 @@ def first_stop_length(new_tokens, tokenizer, keywords):
         return any(k in text for k in keywords)
 
     n_txt = None
-    if len(toks) >= 2 and has(len(toks)):
+    if len(toks) <= LINEAR_SCAN_MAX:
+        # short answers (the common case): exactly the reference's loop, prefix by prefix -- no assumption about the decoder at all
+        n_txt = next((n for n in range(2, len(toks) + 1) if has(n)), None)
+    elif has(len(toks)):
         lo, hi = 2, len(toks)                       # invariant: has(hi)
         while lo < hi:
             mid = (lo + hi) // 2
@@ -49,6 +57,11 @@ def first_stop_length(new_tokens, tokenizer, keywords):
             else:
                 lo = mid + 1
         n_txt = hi
+        if n_txt > 2 and has(n_txt - 1):            # not monotone for this tokenizer / keyword: do what the reference does, token by token
+            n_txt = next(n for n in range(2, len(toks) + 1) if has(n))
+    elif "\ufffd" in tokenizer.batch_decode([toks], skip_special_tokens=True)[0]:
+        # has(len) is False, yet a lossy decoder (replacement characters) may have shown the keyword at a shorter prefix: only a scan can tell
+        n_txt = next((n for n in range(2, len(toks)) if has(n)), None)
     if n_id is None:
         return n_txt
     return n_id if n_txt is None else min(n_id, n_txt)
