@@ -14,16 +14,7 @@
 // of one d).  The S accumulator's key order inside a 16-key group is {0-3, 8-11 | 4-7, 12-15} per half-wave, which is exactly
 // two such 4-key reads per lane.  (Round 1 first transposed V through registers with ds_write_b16: 8-way bank conflicts on the
 // writes -- SQ_LDS_BANK_CONFLICT was 48 % of SQ_LDS_IDX_ACTIVE -- and 40 VGPRs of staging buffers.)
-// Keys are processed in chunks of CB key blocks with an online softmax so the same kernel covers N=257 (224 px) and N=577 (336 px).
-//
-// X1 variant (round 3): CLIP's token count is 32 k + 1 (257 = 8 * 32 + 1, 577 = 18 * 32 + 1).  Padding that to k + 1 blocks of 32 made a
-// ninth (nineteenth) query block with ONE live query and a key block with ONE live key: 81 block pairs of MFMA + softmax work for 64 + a
-// sliver (26 % over).  X1 treats the odd token out separately:
-//   * as a KEY it is one more score per query: a 64-term dot product on the VALU (v_dot2) from the Q fragments already in registers, joined to
-//     the last chunk's softmax, and one rank-1 update of O;
-//   * as a QUERY it is a 1 x N attention row: the four waves each take a quarter of the keys (one key per lane: dot products straight from the
-//     K image, p.V through a 16-lane x 4-key-group split), their partial (max, sum, O) are merged through LDS by wave 0.
-// The k main blocks then need no masking at all, and 8 query blocks over 4 waves (224 px) is an even split.
+// Keys are processed in chunks of 96 with an online softmax so the same kernel covers N=257 (224 px) and N=577 (336 px).
 #include <stdlib.h>
 
 #include <type_traits>
@@ -33,14 +24,14 @@
 namespace {
 
 constexpr int HD = 64;        // CLIP-L head_dim
+constexpr int CB = 3;         // key blocks (of 32) per online-softmax chunk
 
 struct AttnArgs {
     const char* qkv;   // [T*N, ld] 16-bit: q at col 0, k at col C, v at col 2C (fused qkv GEMM output)
     char* out;         // [T*N, ldo] 16-bit, head h at columns h*64
     int ld, ldo;
     int N, C, heads;
-    int nkb;           // key / query blocks of 32: ceil(N/32), or (N-1)/32 main blocks in the X1 variant
-    int pwn;           // X1: floats of per-wave probability scratch
+    int nkb;           // ceil(N/32)
     float scale_log2e; // d^-0.5 * log2(e)
 #ifdef PGV_LAB
     int abl;           // lab builds only (-DPGV_LAB, PGV_ATTN_ABLATE): 1 = no V staging, 2 = no query loop, 4 = no K staging,
@@ -53,27 +44,14 @@ struct AttnArgs {
 #define PGV_ATTN_ABL(p) 0          // the release library has no switch that changes results
 #endif
 
-template <typename T> __device__ __forceinline__ float dot8(typename T::v8 a, typename T::v8 b, float acc);
-template <> __device__ __forceinline__ float dot8<TF16>(half8_t a, half8_t b, float acc) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_fdot2(half2_t{a[2 * i], a[2 * i + 1]}, half2_t{b[2 * i], b[2 * i + 1]}, acc, false);
-    return acc;
-}
-template <> __device__ __forceinline__ float dot8<TBF16>(bf16x8_t a, bf16x8_t b, float acc) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_fdot2_f32_bf16(bf16x2_t{a[2 * i], a[2 * i + 1]}, bf16x2_t{b[2 * i], b[2 * i + 1]}, acc, false);
-    return acc;
-}
-
-// CB = key blocks (of 32) per online-softmax chunk; X1 = the token count is 32 * nkb + 1 and the odd token is handled apart (nkb = main blocks)
-template <typename T, int ABL, int CB, bool X1>
+template <typename T, int ABL>
 __global__ __launch_bounds__(256) void vit_attn_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nw = blockDim.x >> 6;
     const int t = blockIdx.x / p.heads, h = blockIdx.x - t * p.heads;
-    const int N = p.N, npad = p.nkb * 32 + (X1 ? 8 : 0);     // X1: the odd token's K / V row sits at index nkb * 32, in a ninth 8-row DMA group
+    const int N = p.N, npad = p.nkb * 32;
     char* Ks = smem;                               // [npad][128 B], chunk-swizzled
     char* Vs = smem + (size_t)npad * 128;          // [npad][128 B], chunk bit 2 flipped on rows with (row >> 1) & 1
     int* qctr = (int*)(Vs + (size_t)npad * 128);   // next unassigned query block
@@ -127,81 +105,6 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(AttnArgs p) {
     __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): K / V DMA and the first Q fragments
     __syncthreads();
 
-    const float NEG = -1e30f;            // raw-score domain: NEG * scale is still hugely negative, exp2 -> 0
-    const int kx = p.nkb * 32;           // X1: index of the odd token (as key: LDS row kx; as query: row0 + kx)
-    if constexpr (X1) {
-        // ---- the odd token as a QUERY: a 1 x N attention row, a quarter of the keys per wave, one key per lane ----
-        float* scratch = (float*)(smem + (size_t)npad * 256 + 16);
-        float* Pw = scratch + w * p.pwn;                                  // this wave's probabilities, in key-list order
-        float* part = scratch + 4 * p.pwn;                                // [4 waves][68]: partial O (64), max, sum
-        const int per = kx >> 2;                                          // main keys per wave (blockDim is 4 waves)
-        const int cnt = per + (w == 0 ? 1 : 0);                           // wave 0's list ends with the odd key
-        typename T::v8 qx[8];                                             // the odd query's 64 values, the same in every lane
-        const char* qxp = qbase + (row0 + kx) * p.ld * 2;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) qx[c] = *(const typename T::v8*)(qxp + c * 16);
-        const int nit = (cnt + 63) >> 6;
-        float mloc = NEG;
-        for (int it = 0; it < nit; ++it) {
-            const int tpos = it * 64 + lane;
-            const bool ok = tpos < cnt;
-            const int row = (ok && tpos < per) ? w * per + tpos : kx;
-            const char* kr = Ks + (size_t)row * 128;
-            const int swz = (row >> 1) & 7;
-            float sc = 0.f;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) sc = dot8<T>(*(const typename T::v8*)(kr + ((c ^ swz) << 4)), qx[c], sc);
-            sc = ok ? sc * p.scale_log2e : NEG;
-            Pw[tpos] = sc;
-            mloc = fmaxf(mloc, sc);
-        }
-        const float mw = wave_max(mloc);
-        float lloc = 0.f;
-        for (int it = 0; it < nit; ++it) {
-            const int tpos = it * 64 + lane;
-            const float pv = (tpos < cnt) ? __builtin_amdgcn_exp2f(Pw[tpos] - mw) : 0.f;
-            Pw[tpos] = pv;
-            lloc += pv;
-        }
-        const float lw = wave_sum(lloc);
-        __builtin_amdgcn_wave_barrier();
-        // p . V: lane (g4, dq) sums keys g4, g4 + 4, ... of the list for d = 4 dq .. 4 dq + 3
-        const int g4 = lane >> 4, dq = lane & 15;
-        f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
-        const int nj = (cnt + 3) >> 2;
-        for (int j = 0; j < nj; ++j) {
-            const int tpos = g4 + 4 * j;
-            const bool ok = tpos < cnt;
-            const int row = (ok && tpos < per) ? w * per + tpos : kx;
-            const float pv = ok ? Pw[tpos] : 0.f;
-            const typename T::v4 vv = *(const typename T::v4*)(Vs + (size_t)row * 128 + (((dq >> 1) ^ (((row >> 1) & 1) << 2)) << 4) + (dq & 1) * 8);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] += pv * (float)vv[e];
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { acc[e] += __shfl_xor(acc[e], 16, 64); acc[e] += __shfl_xor(acc[e], 32, 64); }
-        if (lane < 16) *(f32x4_t*)(part + w * 68 + 4 * dq) = acc;
-        if (lane == 0) { part[w * 68 + 64] = mw; part[w * 68 + 65] = lw; }
-        __syncthreads();
-        if (w == 0 && lane < 16) {
-            float m = part[64];
-#pragma unroll
-            for (int u = 1; u < 4; ++u) m = fmaxf(m, part[u * 68 + 64]);
-            f32x4_t o4 = {0.f, 0.f, 0.f, 0.f};
-            float l = 0.f;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {                                 // fixed order: the result does not depend on which wave finished first
-                const float a = __builtin_amdgcn_exp2f(part[u * 68 + 64] - m);
-                l += a * part[u * 68 + 65];
-                const f32x4_t pu = *(const f32x4_t*)(part + u * 68 + 4 * lane);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o4[e] += a * pu[e];
-            }
-            const float inv = 1.0f / l;
-            *(u32x2_t*)(p.out + ((row0 + kx) * p.ldo + h * HD + 4 * lane) * 2) = pack4<T>(o4[0] * inv, o4[1] * inv, o4[2] * inv, o4[3] * inv);
-        }
-    }
-
     const int sw = (lane >> 1) & 7;
     int koffs[4];
 #pragma unroll
@@ -209,6 +112,7 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(AttnArgs p) {
     // transposing V reads: lane i of a 16-lane group g addresses key (4 hi + i/4) of the 16-key slice, d columns jj*32 + g*16 + (i%4)*4 .. +3
     const int li = lane & 15, lg = (lane >> 4) & 1;
     const int voff0 = (4 * hi + (li >> 2)) * 128 + (((lg * 2 + ((li & 3) >> 1)) ^ (((li >> 3) & 1) << 2)) << 4) + (li & 1) * 8;   // jj = 1: ^ 64
+    const float NEG = -1e30f;            // raw-score domain: NEG * scale is still hugely negative, exp2 -> 0
 
     // S^T of one chunk: key blocks past the end re-read the last one (valid LDS, masked in the softmax) so there are no branches, the 12
     // fragment reads are issued together and the MFMAs of the three independent accumulators interleave.
@@ -233,18 +137,8 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(AttnArgs p) {
             }
     };
     // Online-softmax update with one chunk of scores and O^T += V^T . P^T.  MASK: the chunk may hold keys >= N.
-    auto absorb = [&](int kb0, f32x16_t (&s)[CB], f32x16_t (&o)[2], float& mrun, float& lrun, auto mask_tag, const typename T::v8 (&qf)[4]) __attribute__((always_inline)) {
-        constexpr bool LAST = decltype(mask_tag)::value;        // the last chunk of a query block
-        constexpr bool MASK = LAST && !X1;                      // ... which is the only one that can hold keys >= N (never in the X1 variant)
-        // X1: the odd key joins the last chunk: its K fragment (matching the Q fragments' d ranges) and this lane's 32 V values
-        typename T::v8 kxf[X1 ? 4 : 1];
-        typename T::v4 vxf[X1 ? 8 : 1];
-        if constexpr (X1 && LAST) {
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) kxf[kk] = *(const typename T::v8*)(Ks + (size_t)kx * 128 + ((kk * 2 + hi) << 4));       // (kx >> 1) & 7 == 0: no swizzle
-#pragma unroll
-            for (int u = 0; u < 8; ++u) vxf[u] = *(const typename T::v4*)(Vs + (size_t)kx * 128 + (u << 4) + hi * 8);              // d = (u >> 2) * 32 + 8 (u & 3) + 4 hi ..
-        }
+    auto absorb = [&](int kb0, f32x16_t (&s)[CB], f32x16_t (&o)[2], float& mrun, float& lrun, auto mask_tag) __attribute__((always_inline)) {
+        constexpr bool MASK = decltype(mask_tag)::value;
         // V^T fragments of the chunk: issued first, their LDS latency hides under the softmax arithmetic
         typename T::v8 vf[CB][2][2];
 #pragma unroll
@@ -282,13 +176,6 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(AttnArgs p) {
                 for (int e = 0; e < 16; ++e) cmax = fmaxf(cmax, s[c][e]);
             cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
         }
-        float sx = 0.f;
-        if constexpr (X1 && LAST) {
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) sx = dot8<T>(kxf[kk], qf[kk], sx);     // this half's 32 of the 64 terms
-            sx += __shfl_xor(sx, 32, 64);
-            cmax = fmaxf(cmax, sx);
-        }
         const float mnew = fmaxf(mrun, cmax * p.scale_log2e);
         const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
         mrun = mnew;
@@ -304,11 +191,6 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(AttnArgs p) {
                 s[c][e] = pv[0]; s[c][e + 1] = pv[1];
                 psum2 += pv;
             }
-        float px = 0.f;
-        if constexpr (X1 && LAST) {
-            px = __builtin_amdgcn_exp2f(sx * p.scale_log2e - mnew);
-            psum2[0] += hi == 0 ? px : 0.f;          // both halves of a query's lane pair hold px: count it once in the row sum
-        }
         lrun = lrun * alpha + (psum2[0] + psum2[1]);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -327,12 +209,6 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(AttnArgs p) {
                     o[j] = T::mfma32(vf[c][ks][j], pa, o[j]);
                 }
             }
-        if constexpr (X1 && LAST) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) o[j][e] += px * (float)vxf[j * 4 + (e >> 2)][e & 3];
-        }
     };
 
     const int nblocks = (PGV_ATTN_ABL(p) & 2) ? 0 : p.nkb;
@@ -355,10 +231,10 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(AttnArgs p) {
         int kb0 = 0;
         for (; kb0 + CB < p.nkb; kb0 += CB) {
             scores(kb0, qf, s);
-            absorb(kb0, s, o, mrun, lrun, std::false_type{}, qf);
+            absorb(kb0, s, o, mrun, lrun, std::false_type{});
         }
         scores(kb0, qf, s);
-        absorb(kb0, s, o, mrun, lrun, std::true_type{}, qf);     // only the last chunk can hold keys >= N (or, X1, takes the odd key)
+        absorb(kb0, s, o, mrun, lrun, std::true_type{});     // only the last chunk can hold keys >= N
 
         __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the next block's Q (requested a whole block ago); see load_q
         const float ltot = lrun + __shfl_xor(lrun, 32, 64);
@@ -378,7 +254,7 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(AttnArgs p) {
                 const auto r1 = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
                 piece[j][m] = u32x4_t{r0[0], r1[0], r0[1], r1[1]};           // lanes 0-31: d = 16m .. 16m+7; lanes 32-63: d = 16m+8 .. 16m+15
             }
-        if (X1 || q < N) {
+        if (q < N) {
             char* orow = p.out + ((row0 + q) * p.ldo + h * HD) * 2;
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -388,56 +264,41 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(AttnArgs p) {
     }
 }
 
-// lab A/B: PGV_ATTN_X1=0 padded kernel, =2 X1 with two key blocks per chunk instead of four (224 px); results agree to rounding
-static int x1_mode() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("PGV_ATTN_X1"); v = e ? atoi(e) : 1; }
-    return v;
-}
-static bool x1_cb4() { return x1_mode() != 2; }
-
 }  // namespace
 
 int pgv_launch_vit_attn(pgv_ctx* ctx, int dtype, const void* qkv, int ld, void* out, int ldo, int T, int N, int C, int heads, hipStream_t s) {
     PGV_CHECK(C == heads * HD, "vit_attn: head_dim must be 64 (hidden %d, heads %d)", C, heads);
     AttnArgs a;
     a.qkv = (const char*)qkv; a.out = (char*)out; a.ld = ld; a.ldo = ldo; a.N = N; a.C = C; a.heads = heads;
+    a.nkb = (N + 31) / 32;
+    const int npad = a.nkb * 32;
     a.scale_log2e = 0.125f * 1.4426950408889634f;
-    // CLIP token counts are 32 k + 1 (257, 577): the X1 variant handles the odd token apart; its chunk size must divide k
-    const int k = (N - 1) / 32;
-    const int x1cb = (x1_mode() != 0 && N % 32 == 1 && k >= 2) ? ((k % 4 == 0 && x1_cb4()) ? 4 : (k % 3 == 0) ? 3 : (k % 2 == 0) ? 2 : 0) : 0;
-    a.nkb = x1cb ? k : (N + 31) / 32;
-    a.pwn = x1cb ? ((k * 8 + 1 + 63) / 64) * 64 : 0;
-    const int npad = a.nkb * 32 + (x1cb ? 8 : 0);
 #ifdef PGV_LAB
     { static int abl = -1; if (abl < 0) { const char* e = getenv("PGV_ATTN_ABLATE"); abl = e ? atoi(e) : 0; } a.abl = abl; }
 #endif
-    const size_t lds = (size_t)npad * 256 + 16 + (x1cb ? (size_t)4 * a.pwn * 4 + 4 * 68 * 4 : 0);    // K + V images, the query-block counter, X1 scratch
+    const size_t lds = (size_t)npad * 256 + 16;    // K + V images + the query-block counter
     PGV_CHECK(lds <= 160 * 1024, "vit_attn: %d tokens per frame need %zu B of LDS (> 160 KiB)", N, lds);
     const int nw = 4;
     pgv_prof_begin(ctx, 1, s);
-#define PGV_ATTN_LAUNCH(T_, ABL_, CB_, X1_) do { \
+#define PGV_ATTN_LAUNCH(T_, ABL_) do { \
         static bool cfg = false; \
-        if (!cfg) { PGV_HIP(hipFuncSetAttribute((const void*)vit_attn_kernel<T_, ABL_, CB_, X1_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); cfg = true; } \
-        hipLaunchKernelGGL((vit_attn_kernel<T_, ABL_, CB_, X1_>), dim3(T * heads), dim3(nw * 64), lds, s, a); } while (0)
-#define PGV_ATTN_BY_SHAPE(T_) do { \
-        if (x1cb == 4) PGV_ATTN_LAUNCH(T_, 0, 4, true); else if (x1cb == 3) PGV_ATTN_LAUNCH(T_, 0, 3, true); \
-        else if (x1cb == 2) PGV_ATTN_LAUNCH(T_, 0, 2, true); else PGV_ATTN_LAUNCH(T_, 0, 3, false); } while (0)
+        if (!cfg) { PGV_HIP(hipFuncSetAttribute((const void*)vit_attn_kernel<T_, ABL_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); cfg = true; } \
+        hipLaunchKernelGGL((vit_attn_kernel<T_, ABL_>), dim3(T * heads), dim3(nw * 64), lds, s, a); } while (0)
     if (dtype == PGV_F16) {
-        PGV_ATTN_BY_SHAPE(TF16);
+        PGV_ATTN_LAUNCH(TF16, 0);
     } else if (dtype == PGV_BF16) {
 #ifndef PGV_LAB
-        PGV_ATTN_BY_SHAPE(TBF16);
+        PGV_ATTN_LAUNCH(TBF16, 0);
 #else
-        if (x1cb || (a.abl & 0x78) == 0) { PGV_ATTN_BY_SHAPE(TBF16); }
-        else switch (a.abl & 0x78) {                 // fine-grained ablations exist for bf16 and the padded kernel only
-            case 8: PGV_ATTN_LAUNCH(TBF16, 8, 3, false); break;
-            case 16: PGV_ATTN_LAUNCH(TBF16, 16, 3, false); break;
-            case 32: PGV_ATTN_LAUNCH(TBF16, 32, 3, false); break;
-            case 64: PGV_ATTN_LAUNCH(TBF16, 64, 3, false); break;
-            case 48: PGV_ATTN_LAUNCH(TBF16, 48, 3, false); break;
-            case 72: PGV_ATTN_LAUNCH(TBF16, 72, 3, false); break;
-            case 120: PGV_ATTN_LAUNCH(TBF16, 120, 3, false); break;
+        switch (a.abl & 0x78) {                      // fine-grained ablations exist for bf16 only
+            case 0: PGV_ATTN_LAUNCH(TBF16, 0); break;
+            case 8: PGV_ATTN_LAUNCH(TBF16, 8); break;
+            case 16: PGV_ATTN_LAUNCH(TBF16, 16); break;
+            case 32: PGV_ATTN_LAUNCH(TBF16, 32); break;
+            case 64: PGV_ATTN_LAUNCH(TBF16, 64); break;
+            case 48: PGV_ATTN_LAUNCH(TBF16, 48); break;
+            case 72: PGV_ATTN_LAUNCH(TBF16, 72); break;
+            case 120: PGV_ATTN_LAUNCH(TBF16, 120); break;
             default: pgv_set_error("vit_attn: unsupported ablation %d", a.abl); return PGV_EINVAL;
         }
 #endif
@@ -445,7 +306,6 @@ int pgv_launch_vit_attn(pgv_ctx* ctx, int dtype, const void* qkv, int ld, void* 
         pgv_set_error("vit_attn: unsupported dtype %d", dtype);
         return PGV_EINVAL;
     }
-#undef PGV_ATTN_BY_SHAPE
 #undef PGV_ATTN_LAUNCH
     PGV_HIP(hipGetLastError());
     pgv_prof_end(ctx, 1, s, 4.0 * (double)T * heads * (double)N * N * HD, 2.0 * 4.0 * (double)T * N * C);
