@@ -8,9 +8,13 @@ video_chatgpt/model/video_chatgpt.py:193-251 driven over 32 / 40 layers by the g
   * 13B fp8 (config 5): 40 layers, e4m3 weights with per-row power-of-two scales, fp16 activations; the oracle runs on the DEQUANTISED
     weights read back from the library (pgv_llm_get_weight: what prefill and decode actually multiply with; one matrix is also checked
     against the CPU twin of the quantiser).  Same bar as 7B: logits bounded, 16 free-running tokens exact, margin floor asserted.
-    (bf16 activations -- the bench dtype -- carry 8x the rounding: measured 7.4e-2 normwise on the logits at 40 layers against 1.6e-2 at 2
-    layers, i.e. the same sqrt(depth) growth; at that noise a random model's 16-step greedy run has near-ties whatever the seed, so the
-    token-exact bar is stated in fp16 and bf16 is bounded at 2 layers in tests/test_gpu_llm.py.)
+  * bf16 (the dtype bench.py's headline runs in; 7B 32 layers, and 13B 40 layers with fp8 weights = config 5 as benched): bf16 carries 8x the
+    rounding, so a free-running 16-token comparison hits near-ties whatever the seed.  Instead 96 / 160 seeded continuation tokens are
+    TEACHER-FORCED, every visited position is compared with the fp32 oracle's logits (one causal pass), the argmax is asserted wherever the
+    oracle's margin exceeds 6 sigma of the measured per-logit noise, and at least 12 such positions must exist (26 / 20 do).
+  * Tolerances are tied to a YARDSTICK: the reference's own VideoChatGPTLlamaForCausalLM run in 16 bits on the host for the same case
+    (tests/golden/yardstick.npz, oracle/gen_yardstick.py); this path must stay within 1.25 x the reference's own distance from the fp32
+    oracle (measured: 0.59 x fp16, 0.56 x bf16 at 7B; 0.39 x / 0.51 x at 13B fp8), plus regression pins at 1.2 x what it measured.
 
 The oracle keeps the 16-bit checkpoint tensors and converts per use (or caches fp32 copies when the host has the memory).
 """
@@ -146,7 +150,7 @@ def test_13b_full_depth_fp8_weights_fp16_token_exact(ctx, golden_dir):
     assert worst < TOL_13B_FP8_FP16
 
 
-def _teacher_forced_check(tag, m, cfg, w, ids, feats, cont, dtype, golden_dir, yard_case, n_min=12, sigmas=6.0):
+def _teacher_forced_check(tag, m, cfg, w, ids, feats, cont, dtype, golden_dir, yard_case, pin_prefill, pin_worst, n_min=12, sigmas=6.0):
     """Teacher-force `cont` through the HIP model and compare every visited position with the fp32 oracle's logits (one causal pass):
     logits error bounded by the yardstick, and at every position whose oracle top-1/top-2 margin exceeds `sigmas` x the MEASURED per-logit
     noise of this run (std over the vocabulary of hip - oracle at that position) the argmax must agree.  At least n_min positions must
@@ -175,7 +179,8 @@ def _teacher_forced_check(tag, m, cfg, w, ids, feats, cont, dtype, golden_dir, y
           f"16-bit run (prefill): {e_ref:.3e}; argmax checked at {checked} positions (margin > {sigmas} sigma), all agree; "
           f"unfiltered agreement {agree_all}/{len(errs)}")
     assert checked >= n_min, f"only {checked} positions had a margin above {sigmas} sigma of the measured noise"
-    assert errs[0] < YARD_FACTOR * e_ref and worst < 1.6 * YARD_FACTOR * e_ref, (errs[0], worst, e_ref)
+    assert errs[0] < YARD_FACTOR * e_ref, (errs[0], e_ref)          # the yardstick (prefill position: the one the reference run covers)
+    assert errs[0] < pin_prefill and worst < pin_worst, (errs[0], worst)          # regression pins: 1.2 x measured on MI355X
     return errs[0], worst, e_ref
 
 
@@ -187,7 +192,8 @@ def test_7b_full_depth_bf16_teacher_forced(ctx, golden_dir):
     c, cfg, w, m = _build("7b", torch.bfloat16)
     ids, feats = fd.make_prompt(cfg, c["prompt_seed"])
     cont = fd.teacher_tokens(cfg, c["prompt_seed"], fd.N_TEACHER["7b"])
-    _teacher_forced_check("7b bf16", m, cfg, w, ids, feats, cont, torch.bfloat16, golden_dir, "7b_bf16")
+    # measured on MI355X: prefill 5.45e-2 (the reference's own bf16 run: 9.81e-2), worst of the 97 positions 6.54e-2, 26 positions checked
+    _teacher_forced_check("7b bf16", m, cfg, w, ids, feats, cont, torch.bfloat16, golden_dir, "7b_bf16", pin_prefill=6.6e-2, pin_worst=7.9e-2)
 
 
 def test_13b_full_depth_fp8_weights_bf16_teacher_forced(ctx, golden_dir):
@@ -201,4 +207,5 @@ def test_13b_full_depth_fp8_weights_bf16_teacher_forced(ctx, golden_dir):
     gc.collect()
     ids, feats = fd.make_prompt(cfg, c["prompt_seed"])
     cont = fd.teacher_tokens(cfg, c["prompt_seed"], fd.N_TEACHER["13b"])
-    _teacher_forced_check("13b fp8 bf16", m, cfg, w, ids, feats, cont, torch.bfloat16, golden_dir, "13b_fp8_bf16")
+    # measured on MI355X: prefill 6.73e-2 (reference bf16 on the same dequantised weights: 1.33e-1), worst of 161 positions 9.44e-2, 20 checked
+    _teacher_forced_check("13b fp8 bf16", m, cfg, w, ids, feats, cont, torch.bfloat16, golden_dir, "13b_fp8_bf16", pin_prefill=8.1e-2, pin_worst=1.14e-1)
