@@ -61,7 +61,7 @@ def parse():
                     help="skip the runner-level measurement (side field `runner`: synthetic .npy clips on local disk through "
                          "video_llava_amd.eval.run_inference_qa_activitynet.run_inference -- file discovery, frame sampling, tokenisation, "
                          "detokenisation and the JSON dump included)")
-    ap.add_argument("--runner-groups", type=int, default=3, help="groups of --clips-per-gpu clips the runner measurement answers (after one warm-up group)")
+    ap.add_argument("--runner-groups", type=int, default=4, help="groups of --clips-per-gpu clips the runner measurement answers (after one warm-up group)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-port", action="store_true", help="additionally time this repo's own CPU oracle (reported under cpu_baseline.port)")
     ap.add_argument("--overlap-vision", action="store_true",

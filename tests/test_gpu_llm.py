@@ -432,3 +432,40 @@ def test_plain_decode_step_after_an_eos_terminated_run(ctx, golden_dir):
         o.step(t)
     want = o.step(toks_ref[3])[0]
     assert rel(lg[0], want) < 1e-3
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-3), (torch.bfloat16, 1.6e-2)])
+def test_folded_rmsnorm_outlier_channels_and_wide_gammas(ctx, dtype, tol):
+    """The RMSNorm folded into the decode GEMVs (and the prefill norm) rounds round16(resid * gamma) BEFORE the normalisation, so its
+    overflow / underflow envelope differs from HF's (x * rstd).half() * gamma.  Random-init fixtures have gamma = 1 +- 0.1 and no outliers;
+    released LLaMA checkpoints have massive-activation channels (~1e3 x the rest) and gammas spanning 1e-2 .. 10.  This case injects both:
+    four embedding columns at 300 - 2000 x the typical magnitude, every norm weight log-uniform in [0.02, 8].  Prefill + 6 decode steps against
+    the fp32 oracle; the logits must stay finite and within 2 x the plain-fixture tolerance (fp16: overflow would show up as inf / nan)."""
+    cfg = synth.LLAMA_TINY
+    w = synth.make_llama_weights(cfg, seed=31, head_std=0.08)
+    rng = np.random.default_rng(32)
+    for k in list(w):
+        if k.endswith("layernorm.weight") or k == "model.norm.weight":
+            w[k] = np.exp(rng.uniform(np.log(0.02), np.log(8.0), w[k].shape)).astype(np.float32)
+    emb = w["model.embed_tokens.weight"]
+    for col, scale in zip((5, 100, 101, 400), (300.0, 800.0, 2000.0, 1200.0)):
+        emb[:, col] *= scale                                           # residual values up to ~2000 x 0.08 x 3 = 500 in these channels
+    m = _model(cfg, w, dtype)
+    V = 24
+    PATCH, START, END = cfg.vocab - 3, cfg.vocab - 2, cfg.vocab - 1
+    ids = [1] + rng.integers(3, cfg.vocab - 3, 9).tolist() + [START] + [PATCH] * V + [END] + rng.integers(3, cfg.vocab - 3, 5).tolist()
+    feats = torch.from_numpy(rng.standard_normal((V, 1024), dtype=np.float32))
+    o = ollm.LlamaOracle(w, cfg)
+    ref = o.prefill(ids, feats, START, END, PATCH)[0]
+    kv, nxt, lg = m.prefill([ids], feats.to(dtype), 64, want_logits=True)
+    assert bool(torch.isfinite(lg).all())
+    worst = rel(lg[0], ref)
+    peak = float(torch.as_tensor(w["model.embed_tokens.weight"]).abs().max())
+    for _ in range(6):
+        tok = int(ref.argmax())
+        ref = o.step(tok)[0]
+        nxt, lg = m.decode_step(kv, torch.tensor([tok], dtype=torch.int32, device=DEV), want_logits=True)     # teacher-forced with the oracle's token
+        assert bool(torch.isfinite(lg).all())
+        worst = max(worst, rel(lg[0], ref))
+    print(f"folded RMSNorm with outlier channels (|embed| up to {peak:.0f}) and gammas in [0.02, 8], {dtype}: worst logits rel err {worst:.3e}")
+    assert worst < tol

@@ -50,17 +50,21 @@ def answer_tasks(args, tasks, components, load_frames, rank, world):
     use_se = model.get_model().vision_config.use_vid_start_end
     stop_strs = {}
 
+    from ..feature_extraction import PinnedRing
+    ring = PinnedRing()
+
     def prepare(indices):
         """HOST half of a group, run one group ahead on the prefetch thread (parallel.run_sharded): decode / sample the frames of the group's
         distinct clips into pinned memory.  -> {path: frames | Exception}"""
         from ..feature_extraction import pin_frames
+        ring.new_group()
         clips = {}
         for idx in indices:
             path = tasks[idx]["path"]
             if path is None or path in clips:
                 continue
             try:
-                clips[path] = pin_frames(load_frames(path))
+                clips[path] = pin_frames(load_frames(path), ring)
             except Exception as e:                                     # noqa: BLE001 -- reported per task below, like the reference's except
                 clips[path] = e
         return clips

@@ -45,7 +45,36 @@ class NativeFrames:
         return resize_nearest(self.array, self.shape)
 
 
-def pin_frames(frames):
+class PinnedRing:
+    """Page-locked host buffers for the runners' prefetch thread, reused instead of re-allocated (hipHostMalloc of 15 MB costs milliseconds
+    per clip).  Two generations alternate: the buffers handed out for group g + 2 are those of group g, whose uploads completed before its
+    answers were read back -- which happens before group g + 2 is prepared (parallel.run_sharded prepares exactly one group ahead)."""
+
+    def __init__(self):
+        self._gen = [[], []]
+        self._turn = 0
+        self._next = 0
+
+    def new_group(self):
+        self._turn ^= 1
+        self._next = 0
+
+    def take(self, shape):
+        pool = self._gen[self._turn]
+        n = int(np.prod(shape))
+        if self._next < len(pool) and pool[self._next].numel() >= n:
+            buf = pool[self._next]
+        else:
+            buf = torch.empty(max(n, 1), dtype=torch.uint8).pin_memory()
+            if self._next < len(pool):
+                pool[self._next] = buf
+            else:
+                pool.append(buf)
+        self._next += 1
+        return buf[:n].view(*shape)
+
+
+def pin_frames(frames, ring: "PinnedRing | None" = None):
     """Move sampled frames (NativeFrames or a uint8 array) into page-locked host memory so the upload is one asynchronous DMA (called on the
     runners' prefetch thread).  Without a GPU runtime the frames are returned unchanged."""
     if not torch.cuda.is_available():
@@ -53,7 +82,7 @@ def pin_frames(frames):
     arr = frames.array if isinstance(frames, NativeFrames) else frames
     if not (isinstance(arr, np.ndarray) and arr.dtype == np.uint8):
         return frames
-    pinned = torch.empty(arr.shape, dtype=torch.uint8).pin_memory()
+    pinned = ring.take(arr.shape) if ring is not None else torch.empty(arr.shape, dtype=torch.uint8).pin_memory()
     view = pinned.numpy()
     view[...] = arr
     return NativeFrames(view, frames.shape) if isinstance(frames, NativeFrames) else view
