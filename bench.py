@@ -182,13 +182,15 @@ PMC_PREFIX = {"gemm": "gemm_w4", "vit_attn": "vit_attn_kernel", "llm_prefill_att
               "decode_gemv": "gemv_mfma_kernel", "decode_attn": "decode_attn_kernel"}
 
 
-def pmc_traffic(family):
+def pmc_traffic(family, tag="traffic"):
     """HBM-side traffic per launch of a kernel family from the committed rocprofv3 PMC passes (scripts/pmc_traffic.sh ->
     scripts/pmc_summary.py -> profiles/*pmc_traffic.json): FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md) + WRITE_SIZE,
     call-weighted over the family's kernels.  rocprofv3 cannot wrap the process that is being timed, so the counters come from
     a separate run of the same bench command with 9 decode tokens; null when no profile file is present."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    # `tag`: "traffic" = the headline configuration (7B, 16-bit weights); "<llm>_<weights>" for the others (e.g. 13b_fp8), so a side line never
+    # borrows the headline's counters
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*pmc_{tag}.json")))
     if not files or family not in PMC_PREFIX:
         return {"traffic": None}
     d = json.load(open(files[-1]))["kernels"]
@@ -755,7 +757,7 @@ def main():
         roofline["event_calibration"] = cal
         roofline["share_of_step"] = d["ms_per_step_est"] / ms_per_step
         roofline["algorithmic_bytes_per_launch"] = raw[dom]["bytes"] / raw[dom]["launches"] if raw[dom]["bytes"] > 0 else None
-        roofline.update(pmc_traffic(dom))
+        roofline.update(pmc_traffic(dom, "traffic" if (args.llm == "7b" and args.weights == "16bit" and args.image == 224) else f"{args.llm}_{args.weights}"))
 
     if rank == 0:
         line = {
