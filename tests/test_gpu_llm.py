@@ -469,3 +469,41 @@ def test_folded_rmsnorm_outlier_channels_and_wide_gammas(ctx, dtype, tol):
         worst = max(worst, rel(lg[0], ref))
     print(f"folded RMSNorm with outlier channels (|embed| up to {peak:.0f}) and gammas in [0.02, 8], {dtype}: worst logits rel err {worst:.3e}")
     assert worst < tol
+
+
+def test_unfolded_decoder_path_matches_goldens(ctx, golden_dir):
+    """PGV_LLM_NORM_FOLD=0 (a standalone RMSNorm in front of every consumer GEMV, HF's order of operations) is a bisect switch for
+    real-checkpoint regressions; it must reproduce the same reference-generated goldens as the folded default.  The switch is read once per
+    process, so the check runs in a child process."""
+    import subprocess
+    import sys
+    code = f'''
+import sys, os, numpy as np, torch
+sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r}); sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r})
+from oracle import synth
+from helpers import make_model
+g = np.load({os.path.join(golden_dir, "llama_tiny.npz")!r})
+cfg = synth.LLAMA_TINY
+w = synth.make_llama_weights(cfg, seed=int(g["lin_weight_seed"]), head_std=float(g["head_std"]))
+def rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / b.norm())
+for dtype, tol in ((torch.float16, 1e-3), (torch.bfloat16, 8e-3)):
+    m = make_model(cfg, w, dtype)
+    ids, want = g["lin_ids"].tolist(), g["lin_tokens"].tolist()
+    feats = torch.from_numpy(g["lin_feats"]).to(dtype)
+    kv, nxt, lg = m.prefill([ids], feats, 64, want_logits=True)
+    assert rel(lg[0], g["lin_step_logits"][0]) < tol
+    got = [int(nxt[0])]
+    for i in range(1, len(want)):
+        nxt, lg = m.decode_step(kv, nxt, want_logits=True)
+        assert rel(lg[0], g["lin_step_logits"][i]) < tol, i
+        got.append(int(nxt[0]))
+    assert got == want, (got, want)
+    out = m.generate(torch.tensor([ids]), video_spatio_temporal_features=feats[None], do_sample=False, max_new_tokens=len(want), chunk=5)
+    assert out[0, len(ids):].tolist() == want
+print("unfolded ok")
+'''
+    env = dict(os.environ, PGV_LLM_NORM_FOLD="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "unfolded ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])

@@ -329,9 +329,18 @@ extern "C" int pgv_kv_len(const pgv_kv* kv, int b) { return (kv && b >= 0 && b <
 // ---------------------------------------------------------------------------------------------
 // kv->xn holds round16(resid * norm_g) and kv->ssq the `nparts` sum-of-squares partials of resid (folded final RMSNorm): lm_head scales its
 // fp32 accumulators by rstd.
+// PGV_LLM_NORM_FOLD=0: decode with a standalone RMSNorm launch in front of every consumer GEMV (HF's order of operations: normalise, round
+// to 16 bits, multiply) instead of the folded form -- a bisect switch for real-checkpoint regressions, not a fallback: both paths
+// are tested against the same goldens (tests/test_gpu_llm.py::test_unfolded_decoder_path_matches_goldens).
+static bool norm_fold_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("PGV_LLM_NORM_FOLD"); v = (e && e[0] == '0') ? 0 : 1; }
+    return v == 1;
+}
+
 static int lm_head_and_pick(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int B, int eos, int flags, hipStream_t s, int nparts) {
     const int H = m->cfg.hidden, V = m->cfg.vocab;
-    GemvNorm nm; nm.ssq_in = kv->ssq; nm.nparts_in = nparts; nm.hidden = H; nm.eps = m->cfg.eps;
+    GemvNorm nm; nm.ssq_in = nparts > 0 ? kv->ssq : nullptr; nm.nparts_in = nparts; nm.hidden = H; nm.eps = m->cfg.eps;     // nparts 0: kv->xn is already normalised
     const bool greedy = !(flags & AM_SAMPLE);
     if (greedy) { nm.amax_val = kv->amax_val; nm.amax_idx = kv->amax_idx; }
     PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_F32, m->fp8 ? m->q_head : m->lm_head, kv->xn, H, kv->logits, V, V, H, B, s, m->fp8 ? m->s_head : nullptr, &nm));
@@ -420,8 +429,13 @@ extern "C" int pgv_llm_prefill(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, const int32
     }
     // lm_head only on the last position of every sequence (the reference computes all S positions, video_chatgpt.py:226)
     PGV_TRY(pgv_launch_gather_rows(resid, d_last, kv->resid, B, H, s));
-    PGV_TRY(pgv_launch_final_prep(m->dtype, kv->resid, m->norm_g, kv->xn, kv->ssq, B, H, s));
-    PGV_TRY(lm_head_and_pick(ctx, m, kv, B, -1, 0, s, 1));
+    if (norm_fold_enabled()) {
+        PGV_TRY(pgv_launch_final_prep(m->dtype, kv->resid, m->norm_g, kv->xn, kv->ssq, B, H, s));
+        PGV_TRY(lm_head_and_pick(ctx, m, kv, B, -1, 0, s, 1));
+    } else {
+        PGV_TRY(pgv_launch_rmsnorm(m->dtype, kv->resid, m->norm_g, m->cfg.eps, kv->xn, B, H, s));
+        PGV_TRY(lm_head_and_pick(ctx, m, kv, B, -1, 0, s, 0));
+    }
     if (d_logits) PGV_HIP(hipMemcpyAsync(d_logits, kv->logits, (size_t)B * vocab * 4, hipMemcpyDeviceToDevice, s));
     if (d_next) PGV_HIP(hipMemcpyAsync(d_next, kv->d_cur, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
     for (int b = 0; b < kv->B; ++b) kv->h_len[b] = b < B ? h_seq_lens[b] : 0;
@@ -434,7 +448,31 @@ extern "C" int pgv_llm_prefill(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, const int32
 // ---------------------------------------------------------------------------------------------
 // decode
 // ---------------------------------------------------------------------------------------------
+static int decode_enqueue_unfolded(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int eos, int flags, hipStream_t s) {
+    const int H = m->cfg.hidden, I = m->cfg.inter, heads = m->cfg.heads, B = kv->active, L = m->cfg.layers;
+    pgv_prof_begin(ctx, 6, s);
+    PGV_TRY(pgv_launch_embed_tok_norm(m->dtype, kv->d_cur, m->embed, kv->resid, L > 0 ? m->layers[0].in_g : m->norm_g, kv->xn, kv->ssq, B, H, s));   // resid is what matters here
+    pgv_prof_end(ctx, 6, s, 0.0, 0.0);
+    double kv_bytes = 0;
+    for (int b = 0; b < B; ++b) kv_bytes += 2.0 * 2.0 * (double)(kv->h_len[b] + 1) * H;
+    for (int li = 0; li < L; ++li) {
+        const LlmLayer& l = m->layers[li];
+        const bool q8 = m->fp8;
+        PGV_TRY(pgv_launch_rmsnorm(m->dtype, kv->resid, l.in_g, m->cfg.eps, kv->xn, B, H, s));
+        PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_STORE16, q8 ? l.q_wqkv : l.wqkv, kv->xn, H, kv->qkv, 3 * H, 3 * H, H, B, s, q8 ? l.s_wqkv : nullptr, nullptr));
+        PGV_TRY(pgv_launch_decode_attn(ctx, m->dtype, kv->qkv, kv->d_pos, m->rope, kv->Kc[li], kv->Vc[li], kv->ao, B, H, heads, kv->max_seq, kv_bytes, s));
+        PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_RESID, q8 ? l.q_wo : l.wo, kv->ao, H, kv->resid, H, H, H, B, s, q8 ? l.s_wo : nullptr, nullptr));
+        PGV_TRY(pgv_launch_rmsnorm(m->dtype, kv->resid, l.post_g, m->cfg.eps, kv->xn, B, H, s));
+        PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_SWIGLU, q8 ? l.q_wgu : l.wgu, kv->xn, H, kv->act, I, 2 * I, H, B, s, q8 ? l.s_wgu : nullptr, nullptr));
+        PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_RESID, q8 ? l.q_wdown : l.wdown, kv->act, I, kv->resid, H, H, I, B, s, q8 ? l.s_wdown : nullptr, nullptr));
+    }
+    PGV_TRY(pgv_launch_rmsnorm(m->dtype, kv->resid, m->norm_g, m->cfg.eps, kv->xn, B, H, s));
+    PGV_TRY(lm_head_and_pick(ctx, m, kv, B, eos, flags, s, 0));
+    return PGV_OK;
+}
+
 static int decode_enqueue(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int eos, int flags, hipStream_t s) {
+    if (!norm_fold_enabled()) return decode_enqueue_unfolded(ctx, m, kv, eos, flags, s);
     const int H = m->cfg.hidden, I = m->cfg.inter, heads = m->cfg.heads, B = kv->active, L = m->cfg.layers;
     const int nparts = H / 16;                     // one sum-of-squares partial per 16-row workgroup of a residual producer
     // RMSNorm has no launch of its own in decode (GemvArgs, llm_kernels.hip): the kernel that completes the residual also writes
