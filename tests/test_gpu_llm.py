@@ -507,3 +507,4 @@ print("unfolded ok")
     env = dict(os.environ, PGV_LLM_NORM_FOLD="0")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "unfolded ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
