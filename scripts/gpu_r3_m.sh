@@ -1,0 +1,21 @@
+#!/bin/bash
+# Round 3 session m: W-resident tile order (lab variant) vs the band order: parity on the GEMM tests, vision bench A/B; unfolded-decoder test.
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp
+O=gpurun_out/r3m; mkdir -p $O
+timeout 600 python scripts/lab/with_lib.py video_llava_amd/libpgv_wres.so -m pytest tests/test_gpu_vision.py -x -q > $O/pytest_wres.log 2>&1; echo "wres vision tests rc=$?"; tail -2 $O/pytest_wres.log
+timeout 600 python -m pytest tests/test_gpu_llm.py -x -q > $O/pytest_llm.log 2>&1; echo "llm tests rc=$?"; tail -2 $O/pytest_llm.log
+V="--workload vision --steps 10 --warmup 3 --no-host-frames --no-profile-pass"
+for rep in 1 2; do
+  timeout 120 python bench.py $V > $O/vis_band_$rep.json 2> $O/vis.err
+  timeout 120 python scripts/lab/with_lib.py video_llava_amd/libpgv_wres.so bench.py $V > $O/vis_wres_$rep.json 2> $O/vis.err
+done
+python - <<'PY'
+import json, glob
+for f in sorted(glob.glob("gpurun_out/r3m/*.json")):
+    try:
+        d = json.loads([l for l in open(f) if l.startswith("{")][-1])
+        print(f.split("/")[-1], "videos/s %.2f" % d["value"], "clip_ms %.2f" % d["clip_feat_ms_per_step"], "frac %.4f" % d["clip_feat_frac_of_mfma_peak"])
+    except Exception as e:
+        print(f, "ERR", e)
+PY

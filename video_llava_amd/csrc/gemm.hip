@@ -85,11 +85,26 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, un
 }
 constexpr unsigned OOB = 0x80000000u;     // voffset of a lane whose store/load must be dropped
 
-// Tile order: block b runs on XCD b%8, so each XCD gets a contiguous run of tile ids; inside that run tiles are walked
+// Tile order (band order; wide outputs use the W-resident order inside tile_coords_v): block b runs on XCD b%8, so each XCD gets a contiguous run of tile ids; inside that run tiles are walked
 // in bands of GM tile-rows, column-major inside a band, so the ~32 workgroups an XCD runs concurrently form a GM x (32/GM)
 // patch that shares GM A-panels and 32/GM W-panels through the XCD's L2 (instead of 1 A-panel and 32 W-panels).
 // vb = virtual block id (blockIdx.x + i * gridDim.x for a persistent workgroup), nwg = total number of tiles.
 __device__ __forceinline__ void tile_coords_v(int vb, int nwg, int ntm, int ntn, int& tm, int& tn) {
+#ifndef PGV_LAB_BAND_ORDER
+    // W-resident order for wide outputs (qkv: 12 tile columns, fc1: 16): the N tiles are cut into 4 column groups, XCD x owns group x % 4 for
+    // the tile rows of parity x / 4 and walks them row-major (its 32 concurrent tiles = 8 rows x 4 columns).  Its W panels (ntn / 4 of them,
+    // 1.5 - 2 MB at K = 1024) stay in its L2 for the whole launch and every A panel is streamed by 4 XCDs at the same moment, instead of every
+    // XCD re-streaming ALL W panels once per band (fc1: 1.6 of its 2.7 GB of L2-miss traffic was W).  Same tiles, same values; vision bench
+    // 126.6 -> 125.3 ms per 800 frames (A/B on one box, gpurun_out/r3m).  Narrow outputs (out_proj, fc2: 4 tile columns) keep the band
+    // order below: there the roles are reversed (A would be streamed four times).
+    if ((ntn & 3) == 0 && ntn >= 8 && (ntm & 1) == 0) {
+        const int wn = ntn >> 2, xcd = vb & 7, loc = vb >> 3;
+        const int r = loc / wn, c = loc - r * wn;
+        tm = 2 * r + (xcd >> 2);
+        tn = (xcd & 3) * wn + c;
+        return;
+    }
+#endif
     constexpr int GM = 4;
     const int q = nwg >> 3, r = nwg & 7, xcd = vb & 7, loc = vb >> 3;
     const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
