@@ -201,3 +201,27 @@ def test_chat_interface_multi_turn_matches_oracle(ctx, tmp_path):
         assert chat.video_features is None and chat.first_run
     finally:
         type(tower).__call__ = orig_call
+
+
+def test_video_features_batch_equals_per_clip(ctx):
+    """The runners' group path: ONE tower pass over the frames of several clips (ragged frame counts, mixed native resolutions, one clip
+    already at crop size as a plain uint8 array) must give, clip by clip, bit-identical pooled features to `video_features` on the clip alone
+    (the tower is batch-split invariant; the two-lane pass splits the concatenation at a frame that belongs to neither clip boundary)."""
+    from video_llava_amd.feature_extraction import NativeFrames
+    from video_llava_amd.inference import video_features, video_features_batch
+    ccfg = synth.CLIP_TINY
+    tower = _tower(ccfg, synth.make_clip_weights(ccfg, seed=51))
+    S = ccfg.image
+    rng = np.random.default_rng(52)
+    clips = [NativeFrames(rng.integers(0, 256, (23, 40, 52, 3), dtype=np.uint8), (S, S)),
+             NativeFrames(rng.integers(0, 256, (9, 40, 52, 3), dtype=np.uint8), (S, S)),       # same native size as the first: one upload, one ingest
+             NativeFrames(rng.integers(0, 256, (31, 30, 30, 3), dtype=np.uint8), (S, S)),      # another native size (up-sampled)
+             rng.integers(0, 256, (5, S, S, 3), dtype=np.uint8)]                               # already crop-sized: the preprocess-only path
+
+    class IP:
+        crop_size = {"height": S, "width": S}
+    together = video_features_batch(clips, tower, IP())
+    assert len(together) == 4
+    for c, got in zip(clips, together):
+        alone = video_features(c, tower, IP())
+        assert got.shape == alone.shape == (100 + ccfg.patches, 1024) and torch.equal(got, alone)
