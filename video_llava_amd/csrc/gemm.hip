@@ -105,7 +105,11 @@ __device__ __forceinline__ void tile_coords_v(int vb, int nwg, int ntm, int ntn,
         return;
     }
 #endif
+#ifdef PGV_LAB_GM8
+    constexpr int GM = 8;
+#else
     constexpr int GM = 4;
+#endif
     const int q = nwg >> 3, r = nwg & 7, xcd = vb & 7, loc = vb >> 3;
     const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     const int band = t / (GM * ntn);
