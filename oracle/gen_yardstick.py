@@ -90,6 +90,8 @@ def reference_logits(cfg: synth.LlamaCfg, w: dict, ids, feats, tdt) -> torch.Ten
 
 
 def main():
+    if sys.argv[1:] == ["vit"]:
+        return vit_yardstick()
     names = sys.argv[1:] or ["7b_fp16", "7b_bf16"]
     gg._import_reference()
     out = dict(np.load(OUT)) if os.path.exists(OUT) else {}
@@ -119,6 +121,31 @@ def main():
         gc.collect()
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, {k: float(v) for k, v in out.items() if k.endswith("_err")})
+
+
+
+
+def vit_yardstick():
+    """The vision side of the yardstick: HF CLIPVisionModel (the module `initialize_model` builds, video_chatgpt/eval/model_utils.py:134) run in
+    fp16 / bf16 on the host for BASELINE config 1 (ViT-L/14, 8 synthetic frames, the seeds of tests/test_gpu_vision.py), hidden_states[-2][:, 1:]
+    against the fp32 oracle -> tests/golden/yardstick.npz keys vit_l14_8f_{fp16,bf16}_ref_err."""
+    from oracle import vision as ovis
+    gg._import_reference()
+    cfg = synth.CLIP_L14_224
+    w = synth.make_clip_weights(cfg, seed=0)
+    px = ovis.clip_preprocess(synth.make_frames(8, 224, seed=0))
+    truth = ovis.clip_select_features(px, w, cfg)
+    out = dict(np.load(OUT)) if os.path.exists(OUT) else {}
+    for name, tdt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
+        model, _ = gg._hf_clip(cfg, w)
+        model = model.to(tdt)
+        t0 = time.time()
+        with torch.no_grad():
+            feat = model(px.to(tdt), output_hidden_states=True).hidden_states[-2][:, 1:].float()
+        err = float((feat.double() - truth.double()).norm() / truth.double().norm())
+        print(f"[vit_l14_8f_{name}] HF CLIPVisionModel in {name} vs fp32 oracle: normwise {err:.4e} ({time.time() - t0:.0f}s)", flush=True)
+        out[f"vit_l14_8f_{name}_ref_err"] = np.float64(err)
+    np.savez_compressed(OUT, **out)
 
 
 if __name__ == "__main__":

@@ -240,8 +240,11 @@ def test_vit_l14_config1_vs_oracle(ctx, golden_dir, dtype, tol):
     feat = tower(px.to(dtype).to(DEV), output_hidden_states=True).hidden_states[-2][:, 1:]
     ref = ovis.clip_select_features(px, w, cfg)
     e = rel(feat, ref)
-    print(f"ViT-L/14 8 frames {dtype}: normwise rel err vs fp32 oracle = {e:.3e}")
-    assert e < tol
+    # yardstick (oracle/gen_yardstick.py vit): HF CLIPVisionModel itself, run in this dtype on the host for the same frames and weights, sits at
+    # 1.65e-3 (fp16) / 1.32e-2 (bf16) from the fp32 oracle -- the reference's own 16-bit run does not meet the 1e-3 bar this path is held to
+    e_ref = float(np.load(os.path.join(golden_dir, "yardstick.npz"))["vit_l14_8f_fp16_ref_err" if dtype == torch.float16 else "vit_l14_8f_bf16_ref_err"])
+    print(f"ViT-L/14 8 frames {dtype}: normwise rel err vs fp32 oracle = {e:.3e}; HF CLIPVisionModel in the same dtype: {e_ref:.3e}")
+    assert e < tol and e < 1.25 * e_ref
     pooled = ctx.st_pool(feat)
     gold = np.load(os.path.join(golden_dir, "vit_l14_8f_pooled.npz"))["pooled"]
     assert rel(pooled, torch.from_numpy(gold.astype(np.float32))) < tol
