@@ -331,8 +331,11 @@ __global__ __launch_bounds__(256, 1) void gemm_w4(KArgs p) {
         constexpr int which = decltype(which_c)::value;
         if constexpr (!(ABL & 1)) {
             char* dst = smem + (which == 0 ? a_slot : w_slot) * SLOT + (j * 4 + w) * 1024;
+#ifndef PGV_LAB_DMA_AUX
+#define PGV_LAB_DMA_AUX 0               // cache-policy bits of the operand DMA (lab A/B: 1 = sc0, 2 = sc1, 8 = nt ...)
+#endif
             __builtin_amdgcn_raw_ptr_buffer_load_lds(which == 0 ? rsA : rsW, (__attribute__((address_space(3))) void*)dst, 16,
-                                                     which == 0 ? voffA[j] : voffW[j], which == 0 ? a_k : w_k, 0, 0);
+                                                     which == 0 ? voffA[j] : voffW[j], which == 0 ? a_k : w_k, 0, PGV_LAB_DMA_AUX);
         }
     };
     auto advance = [&](auto which_c) __attribute__((always_inline)) {             // cursor -> the same tile kind of the next K-step
