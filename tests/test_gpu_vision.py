@@ -294,6 +294,86 @@ def test_vit_100_frames_properties(ctx):
     assert rel(full[:8, 1:], ref) < 1e-3
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 1e-3), (torch.bfloat16, 8e-3)])
+def test_vit_800_frames_benched_shape(ctx, dtype, tol):
+    """The shape `bench.py` times: 8 clips x 100 frames in ONE tower call = two lanes of 400 frames -> 402 tile rows per
+    lane, an EVEN row count, so the qkv / fc1 GEMMs take the W-resident tile order of csrc/gemm.hip tile_coords_v with 19 - 25 persistent
+    rounds per workgroup -- a branch no 100-frame test enters (2 x 50 frames -> 51 rows, odd -> band order).  Frames are independent, so the
+    800-frame pass must equal the eight 100-frame passes (the reference's per-clip call, video_chatgpt/inference.py:93; batching loop
+    scripts/save_spatio_temporal_clip_features.py:108-121) BIT FOR BIT; the profiled pass of the bench (pgv_prof_enable forces ONE lane:
+    804 tile rows, also even) must too; and the first 8 frames are held to the fp32 oracle like BASELINE config 1."""
+    cfg = synth.CLIP_L14_224
+    w = synth.make_clip_weights(cfg, seed=0)
+    tower = _tower(cfg, w, dtype)
+    frames = np.concatenate([synth.make_frames(100, 224, seed=k) for k in range(8)])            # 8 distinct clips; clip 0 = the config-1 frames
+    px = ctx.preprocess_u8(torch.from_numpy(frames).to(DEV), dtype)
+    full = tower(px).hidden_states[-2]
+    assert full.shape == (800, 257, 1024) and torch.isfinite(full).all()
+    for k in range(8):
+        part = tower(px[100 * k:100 * (k + 1)]).hidden_states[-2]
+        assert torch.equal(full[100 * k:100 * (k + 1)], part), f"clip {k}: the 800-frame pass differs from its 100-frame pass"
+    ctx.prof_enable(True)                                                                       # the bench's profiled pass: one lane, 804 tile rows
+    try:
+        single = tower(px).hidden_states[-2]
+    finally:
+        ctx.prof_enable(False)
+        ctx.prof_reset()
+    assert torch.equal(single, full)
+    ref = ovis.clip_select_features(ovis.clip_preprocess(frames[:8]), w, cfg)
+    e = rel(full[:8, 1:], ref)
+    print(f"800-frame pass {dtype}: first 8 frames vs fp32 oracle {e:.3e}")
+    assert e < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 1e-3), (torch.bfloat16, 8e-3)])
+def test_vit_336_even_row_count(ctx, dtype, tol):
+    """336 px (N = 577): 14 frames in one lane = 8078 rows -> 32 tile rows (even -> W-resident order for qkv / fc1); the same frames in
+    passes of 3 (1731 rows -> 7 tile rows, odd -> band order) must give the same bits, and the first 3 frames agree with the fp32 oracle."""
+    cfg = synth.CLIP_L14_336
+    w = synth.make_clip_weights(cfg, seed=3)
+    tower = _tower(cfg, w, dtype)
+    frames = np.concatenate([synth.make_frames(3, 336, seed=4), synth.make_frames(11, 336, seed=5)])
+    px = ctx.preprocess_u8(torch.from_numpy(frames).to(DEV), dtype)
+    full = tower(px).hidden_states[-2]
+    assert full.shape == (14, 577, 1024)
+    parts = torch.cat([tower(px[i:i + 3]).hidden_states[-2] for i in range(0, 14, 3)])
+    assert torch.equal(full, parts)
+    ref = ovis.clip_select_features(ovis.clip_preprocess(frames[:3]), w, cfg)
+    assert rel(full[:3, 1:], ref) < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N", [(102800, 3072), (102800, 4096), (4096, 3072), (4096, 4096), (205600, 3072)])
+def test_gemm_w_resident_tile_order(ctx, dtype, M, N):
+    """pgv_gemm at the tile grids of the benched ViT pass (K = 1024): M = 102 800 rows = 402 tile rows (one lane of 400 frames), 205 600 =
+    804 (the single-lane profiled pass), 4096 = 16; N = 3072 (qkv, 12 tile columns) and 4096 (fc1, 16) -> the W-resident order
+    (csrc/gemm.hip tile_coords_v: even row count, >= 8 tile columns) with many row pairs per XCD.  Checked against torch fp32, and against
+    the ODD-row-count twin of the same problem (one tile row fewer -> band order): the two orders visit the same tiles with the same K
+    loop, so the shared rows must be bitwise equal."""
+    from video_llava_amd import _lib
+    K = 1024
+    g = torch.Generator(device=DEV).manual_seed(M + N)
+    a = torch.randn(M, K, generator=g, device=DEV).to(dtype)
+    w = (torch.randn(N, K, generator=g, device=DEV) * 0.05).to(dtype)
+    b = torch.randn(N, generator=g, device=DEV)
+    out = ctx.gemm(a, w, b, _lib.EPI_BIAS)
+    tol = 1.5e-3 if dtype == torch.float16 else 8e-3
+    worst = 0.0
+    for r0 in range(0, M, 25700):                                  # reference in row slabs (fp32 [M, N] at once would be 3.4 GB)
+        ref = a[r0:r0 + 25700].float() @ w.float().t() + b
+        got = out[r0:r0 + 25700].float()
+        assert rel(got, ref) < tol
+        worst = max(worst, float((got - ref).abs().max() / ref.abs().max()))
+    assert worst < 0.05
+    M_odd = M - 256                                                # 401 / 803 / 15 tile rows: the band order
+    assert ((M + 255) // 256) % 2 == 0 and ((M_odd + 255) // 256) % 2 == 1
+    twin = ctx.gemm(a[:M_odd], w, b, _lib.EPI_BIAS)
+    assert torch.equal(twin, out[:M_odd])
+    q = ctx.gemm(a, w, b, _lib.EPI_BIAS_QGELU)                     # fc1's activation on the same order
+    q_twin = ctx.gemm(a[:M_odd], w, b, _lib.EPI_BIAS_QGELU)
+    assert torch.equal(q_twin, q[:M_odd])
+
+
 # --------------------------------------------------------------------------------------------------
 # mm_projector (C ABI level; the nn.Module mirror is tested in test_gpu_llm.py)
 # --------------------------------------------------------------------------------------------------

@@ -227,6 +227,73 @@ def test_no_kernel_spills_to_scratch():
     assert not bad, f"kernels spilling VGPRs: {bad[:6]}"
 
 
+def test_gemm_tile_order_is_a_bijection(tmp_path):
+    """The persistent GEMM's tile order (csrc/gemm.hip tile_coords_v: the W-resident order for wide outputs with an even tile-row count,
+    the band order otherwise) must visit every output tile exactly once for every grid the path launches.  The function is not ported: its
+    SOURCE TEXT is cut out of gemm.hip and compiled for the host (it is plain integer arithmetic), then brute-forced over the tile grids of
+    the ViT passes (224 px: N = 257 tokens, 336 px: 577; 1 .. 1024 frames per lane; qkv 12 / fc1 16 / out_proj, fc2 4 tile columns), the
+    LLaMA prefill projections (7B: 48 / 16 / 86; 13B: 60 / 20 / 108 tile columns) and every small grid."""
+    import shutil
+    gxx = shutil.which("g++")
+    assert gxx, "g++ is part of the image"
+    src = open(os.path.join(ROOT, "video_llava_amd", "csrc", "gemm.hip")).read()
+    i = src.index("__device__ __forceinline__ void tile_coords_v")
+    depth, j = 0, src.index("{", i)
+    for j in range(j, len(src)):
+        depth += src[j] == "{"
+        depth -= src[j] == "}"
+        if depth == 0:
+            break
+    fn = src[i:j + 1]
+    assert "wn = ntn >> 2" in fn and "band" in fn            # both orders are in the cut
+    prog = """#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define __device__
+#define __forceinline__ inline
+using std::min;
+""" + fn + """
+int main(int argc, char** argv) {
+    long checked = 0;
+    for (int a = 1; a + 1 < argc; a += 2) {
+        const int ntm = atoi(argv[a]), ntn = atoi(argv[a + 1]), total = ntm * ntn;
+        std::vector<char> seen(total, 0);
+        for (int vb = 0; vb < total; ++vb) {
+            int tm = -1, tn = -1;
+            tile_coords_v(vb, total, ntm, ntn, tm, tn);
+            if (tm < 0 || tm >= ntm || tn < 0 || tn >= ntn || seen[tm * ntn + tn]) { printf("BAD ntm=%d ntn=%d vb=%d -> (%d,%d)\\n", ntm, ntn, vb, tm, tn); return 1; }
+            seen[tm * ntn + tn] = 1;
+        }
+        ++checked;
+    }
+    printf("OK %ld\\n", checked);
+    return 0;
+}
+"""
+    cpp, exe = tmp_path / "tiles.cpp", tmp_path / "tiles"
+    cpp.write_text(prog)
+    subprocess.run([gxx, "-O1", "-o", str(exe), str(cpp)], check=True)
+    grids = set()
+    for tokens in (257, 577):
+        for frames in list(range(1, 130)) + [200, 256, 399, 400, 401, 512, 799, 800, 1000, 1024]:
+            ntm = (frames * tokens + 255) // 256
+            for ntn in (4, 12, 16):
+                grids.add((ntm, ntn))
+        for frames in range(1, 130):
+            grids.add(((frames * (tokens - 1) + 255) // 256, 4))                 # patch-embed GEMM: M = frames x patches
+    for rows in (1, 2, 441, 454, 3528, 7264):                                   # prefill: sum of prompt lengths (1 .. 16 sequences)
+        for ntn in (48, 16, 86, 60, 20, 108, 1, 2, 3, 5, 8, 9, 17):
+            grids.add(((rows + 255) // 256, ntn))
+    for ntm in range(1, 41):
+        for ntn in range(1, 41):
+            grids.add((ntm, ntn))
+    args = [str(x) for g in sorted(grids) for x in g]
+    r = subprocess.run([str(exe), *args], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("OK"), r.stdout + r.stderr
+    assert (402, 12) in grids and (804, 16) in grids                           # the two grids bench.py times
+
+
 # --------------------------------------------------------------------------------------------------
 # offline feature extraction (scripts/save_spatio_temporal_clip_features.py) and the QA runner: host logic
 # --------------------------------------------------------------------------------------------------

@@ -195,7 +195,10 @@ extern "C" int pgv_vit_forward(pgv_ctx* ctx, pgv_vit* v, const void* d_pixels, i
 #ifdef PGV_LAB
     { static int c = -1; if (c < 0) { const char* e = getenv("PGV_VIT_CHUNK"); c = e ? atoi(e) : 0; } if (c > 0) chunk_frames = c; }   // lab: frames per lane and pass
 #endif
-    const int Tc_max = lane_T[0] < chunk_frames ? lane_T[0] : chunk_frames;
+    // the arena holds `lanes` workspaces: a lane's pass is capped at chunk_frames / lanes so the total stays what one lane of chunk_frames took
+    // (with T > max_chunk_frames the arena would otherwise double next to a 13B model + KV cache)
+    const int lane_cap = chunk_frames / lanes > 0 ? chunk_frames / lanes : 1;
+    const int Tc_max = lane_T[0] < lane_cap ? lane_T[0] : lane_cap;
     const size_t Mmax = (size_t)Tc_max * N;
     const int NP = C / 64;             // 64-column pieces of a residual row (partial statistics of the folded LayerNorm)
     const size_t b_resid = pgv_align(Mmax * C * 4), b_xn = pgv_align(Mmax * C * 2), b_qkv = pgv_align(Mmax * 3 * C * 2), b_ao = pgv_align(Mmax * C * 2),
@@ -291,22 +294,31 @@ extern "C" int pgv_vit_forward(pgv_ctx* ctx, pgv_vit* v, const void* d_pixels, i
         return PGV_OK;
     };
     auto pending = [&]() { for (int k = 0; k < lanes; ++k) if (L[k].done < L[k].T) return true; return false; };
-    while (pending()) {
-        int ct0[MAX_LANES], cT[MAX_LANES];
-        for (int k = 0; k < lanes; ++k) {
-            ct0[k] = L[k].t0 + L[k].done;
-            cT[k] = (L[k].T - L[k].done) < Tc_max ? (L[k].T - L[k].done) : Tc_max;
+    auto run = [&]() -> int {
+        while (pending()) {
+            int ct0[MAX_LANES], cT[MAX_LANES];
+            for (int k = 0; k < lanes; ++k) {
+                ct0[k] = L[k].t0 + L[k].done;
+                cT[k] = (L[k].T - L[k].done) < Tc_max ? (L[k].T - L[k].done) : Tc_max;
+            }
+            for (int k = 0; k < lanes; ++k) if (cT[k] > 0) PGV_TRY(embed(L[k], ct0[k], cT[k]));
+            for (int li = 0; li < n_layers; ++li)
+                for (int k = 0; k < lanes; ++k) if (cT[k] > 0) PGV_TRY(layer(L[k], ct0[k], cT[k], li));
+            for (int k = 0; k < lanes; ++k) if (cT[k] > 0) { PGV_TRY(tail(L[k], ct0[k], cT[k])); L[k].done += cT[k]; }
         }
-        for (int k = 0; k < lanes; ++k) if (cT[k] > 0) PGV_TRY(embed(L[k], ct0[k], cT[k]));
-        for (int li = 0; li < n_layers; ++li)
-            for (int k = 0; k < lanes; ++k) if (cT[k] > 0) PGV_TRY(layer(L[k], ct0[k], cT[k], li));
-        for (int k = 0; k < lanes; ++k) if (cT[k] > 0) { PGV_TRY(tail(L[k], ct0[k], cT[k])); L[k].done += cT[k]; }
-    }
+        return PGV_OK;
+    };
+    // Common exit: whatever run() returned, every forked lane is joined back into the caller's stream and the arena is released
+    // (its event recorded) -- a failed pass must not leave aux-lane kernels unordered against the next user of the shared arena.
+    int rc = run();
     for (int k = 1; k < lanes; ++k) {
-        PGV_HIP(hipEventRecord(ctx->ev_join[k - 1], ctx->aux_stream[k - 1]));
-        PGV_HIP(hipStreamWaitEvent(s, ctx->ev_join[k - 1], 0));
+        hipError_t e = hipEventRecord(ctx->ev_join[k - 1], ctx->aux_stream[k - 1]);
+        if (e == hipSuccess) e = hipStreamWaitEvent(s, ctx->ev_join[k - 1], 0);
+        if (e != hipSuccess && rc == PGV_OK) { pgv_set_error("pgv_vit_forward: lane join: %s", hipGetErrorString(e)); rc = PGV_EHIP; }
     }
-    PGV_TRY(pgv_ws_release(ctx, s));
+    const int rel = pgv_ws_release(ctx, s);
+    if (rc != PGV_OK) return rc;
+    PGV_TRY(rel);
     PGV_HIP(hipGetLastError());
     return PGV_OK;
 }
