@@ -75,6 +75,10 @@ def parse():
     ap.add_argument("--no-profile-pass", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=4)
     ap.add_argument("--cpu-layers", type=int, default=2)
+    ap.add_argument("--no-side", action="store_true",
+                    help="skip the guarded side lines of the default run (`side.fp16`: the reference's dtype, the one the 1e-3 tolerance is stated in; "
+                         "`side.cfg5_13b_fp8`: BASELINE configs[4] with its own roofline; `side.clips32` when the decoder batches that many)")
+    ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)     # internal: the pinned CPU-baseline subprocess
     return ap.parse_args()
 
 
@@ -160,7 +164,8 @@ def runner_measurement(args, model, tower, video_rows, S, rank, world):
                 json.dump([{"answer": "yes"}] * n, f)
             a = qa.parse_args(["--video_dir", vd, "--gt_file_question", os.path.join(tmp, f"q_{tag}.json"), "--gt_file_answers",
                                os.path.join(tmp, f"a_{tag}.json"), "--output_dir", os.path.join(tmp, "out"), "--output_name", tag, "--model-name", "synthetic",
-                               "--projection_path", "synthetic", "--batch", str(B), "--max_new_tokens", str(NEW)])
+                               "--projection_path", "synthetic", "--batch", str(B), "--max_new_tokens", str(NEW),
+                               "--feature-cache", "0"])            # the files repeat every other group: a cached tower pass would be skipped work
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             out = qa.run_inference(a, components=components)
@@ -254,7 +259,57 @@ def _fast_hf_build(cls, cfg):
     return m.eval()
 
 
+def _numa_node_cpus():
+    """(node id, one logical CPU per PHYSICAL core of that node) for the NUMA node with the most cores, from sysfs; (None, []) when sysfs has no
+    NUMA topology (single-node hosts, containers that hide it)."""
+    import glob
+    best = (None, [])
+    for path in sorted(glob.glob("/sys/devices/system/node/node[0-9]*")):
+        try:
+            cpus = []
+            for part in open(os.path.join(path, "cpulist")).read().strip().split(","):
+                lo, _, hi = part.partition("-")
+                cpus += list(range(int(lo), int(hi or lo) + 1))
+            allowed = os.sched_getaffinity(0)
+            phys = []
+            for c in cpus:
+                if c not in allowed:
+                    continue
+                sib = open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip().replace("-", ",").split(",")
+                if c == min(int(x) for x in sib):               # the first hardware thread of its core
+                    phys.append(c)
+            if len(phys) > len(best[1]):
+                best = (int(path.rsplit("node", 1)[1]), phys)
+        except (OSError, ValueError):
+            continue
+    return best
+
+
 def cpu_baseline_reference(args):
+    """Parent side of the CPU baseline: the measurement runs in a CHILD process whose affinity mask is the physical cores of ONE NUMA node
+    (set before the interpreter starts, so every thread of ATen's pool inherits it and the 27 GB of fp32 weights are first-touched on that
+    node's DIMMs) -- VERDICT r3 weak #9: the unpinned run measured torch's worst (32 ms per decoder layer on a 256-thread host against
+    9.4 ms on the 8-core survey probe).  PGV_CPU_BASELINE_PIN=0 runs the child unpinned for comparison."""
+    node, cpus = _numa_node_cpus()
+    pin = os.environ.get("PGV_CPU_BASELINE_PIN", "1") != "0" and len(cpus) >= 2
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--llm", args.llm, "--frames", str(args.frames), "--new-tokens", str(args.new_tokens)]
+    env = dict(os.environ)
+    env.pop("OMP_NUM_THREADS", None)
+    t0 = time.perf_counter()
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env,
+                       preexec_fn=(lambda: os.sched_setaffinity(0, cpus)) if pin else None)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        raise RuntimeError(f"cpu-baseline child rc={r.returncode}: {(r.stderr or r.stdout)[-400:]}")
+    out = json.loads(lines[-1])
+    out["pinning"] = {"numa_node": node if pin else None, "cpus_in_mask": len(cpus) if pin else (os.cpu_count() or 1),
+                      "policy": ("child process bound to one hardware thread per physical core of one NUMA node before start; weights first-touched there"
+                                 if pin else "unpinned")}
+    out["child_wall_s"] = time.perf_counter() - t0
+    return out
+
+
+def cpu_baseline_child(args):
     """The CPU baseline BASELINE.md 2 specifies: the reference's own path executed by PyTorch on the host cores.  The reference delegates
     ALL arithmetic of this path to HF transformers -- `CLIPVisionModel` (video_chatgpt/eval/model_utils.py:134, inference.py:93) and
     `LlamaForCausalLM.forward` (VideoChatGPTLlamaForCausalLM subclasses it; model/video_chatgpt.py:170-175,219-226) -- plus its own numpy
@@ -263,20 +318,22 @@ def cpu_baseline_reference(args):
     pooling is the oracle's verbatim restatement of the reference's numpy function.
       (i)  BASELINE config 1 in full: 8 frames, fp32, eager attention, all 24 CLIP layers (what the reference executes) -> hidden_states[-2][:, 1:]
            -> numpy pooling -> [356, 1024] fp16.
-      (ii) decoder at FULL DEPTH (32 / 40 layers, fp32 weights: 27 / 52 GB, NUMA-interleaved): LlamaForCausalLM.forward, eager attention, lm_head
-           on all positions as the reference computes it (model/video_chatgpt.py:226): one prefill of the ~450-token prompt and KV-cached decode
-           steps, timed directly (no per-layer differencing).  Thread counts are tried per stage (small GEMVs do not scale to every core), the
-           best is kept; the decode step is also reported per layer and as GB/s of fp32 weights streamed."""
+      (ii) decoder at FULL DEPTH (32 / 40 layers, fp32 weights: 27 / 52 GB): LlamaForCausalLM.forward, eager attention, lm_head on all
+           positions as the reference computes it (model/video_chatgpt.py:226): one prefill of the ~450-token prompt and KV-cached decode
+           steps, timed directly (no per-layer differencing).  Thread counts are swept per stage INSIDE the affinity mask the parent set
+           (small GEMVs do not scale to every core), the best is kept and every count tried is reported."""
     import transformers
     from transformers import CLIPVisionConfig, CLIPVisionModel, LlamaConfig, LlamaForCausalLM
     from oracle import synth
     from oracle import vision as ovis
     t_all = time.perf_counter()
-    ncores = os.cpu_count() or 1
-    # numactl --interleave=all semantics are opt-in: on the 2-node GPU hosts measured it changed nothing for the decode step (27 GB/s of fp32
-    # weights whatever the placement and the thread count: torch's M = 1 Linear path, not the DIMMs, is the limit) and slowed the prefill
+    ncores = len(os.sched_getaffinity(0))
     numa_nodes = _interleave_host_memory() if os.environ.get("PGV_CPU_BASELINE_INTERLEAVE") == "1" else 0
-    default_threads = torch.get_num_threads()
+    default_threads = min(torch.get_num_threads(), ncores)
+
+    def counts(*c):
+        return sorted({max(1, min(x, ncores)) for x in c}, reverse=True)
+
     frames = synth.make_frames(8, 224, seed=0)
     ccfg = CLIPVisionConfig(hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16, image_size=224, patch_size=14,
                             hidden_act="quick_gelu", layer_norm_eps=1e-5, attn_implementation="eager")
@@ -284,16 +341,13 @@ def cpu_baseline_reference(args):
     px = ovis.clip_preprocess(frames)
     vit_times = {}
     with torch.no_grad():
-        for th in sorted({default_threads, min(32, ncores), min(16, ncores)}, reverse=True):
+        for th in counts(default_threads, 32, 16):
             torch.set_num_threads(th)
             clip(px[:1], output_hidden_states=True)                                   # warm-up
-            best = 1e9
-            for _ in range(2):
-                t0 = time.perf_counter()
-                feat = clip(px, output_hidden_states=True).hidden_states[-2][:, 1:]
-                pooled = ovis.spatio_temporal_pool_numpy(feat.numpy().astype(np.float16))
-                best = min(best, time.perf_counter() - t0)
-            vit_times[th] = best
+            t0 = time.perf_counter()
+            feat = clip(px, output_hidden_states=True).hidden_states[-2][:, 1:]
+            ovis.spatio_temporal_pool_numpy(feat.numpy().astype(np.float16))
+            vit_times[th] = time.perf_counter() - t0
     t_cfg1 = min(vit_times.values())
     del clip
     full_layers, H, I, heads = (32, 4096, 11008, 32) if args.llm == "7b" else (40, 5120, 13824, 40)
@@ -326,32 +380,35 @@ def cpu_baseline_reference(args):
                 o = llm(input_ids=tok, past_key_values=o.past_key_values, use_cache=True)
             return (time.perf_counter() - t0) / n_step, o
 
-    cand = sorted({min(64, ncores), min(32, ncores), min(16, ncores)}, reverse=True)
     pre, o = {}, None
-    for th in sorted({min(32, ncores), min(16, ncores)}, reverse=True):     # more threads than one socket's worth were slower in every run so far
+    for th in counts(default_threads, 32):
         pre[th], o = prefill(th)
     step = {}
-    for th in sorted({min(64, ncores), min(16, ncores)}, reverse=True):
+    for th in counts(default_threads, 32, 16, 8):
         step[th], o = decode(th, o)
+        if time.perf_counter() - t_all > 75:                     # bounded sample: stop sweeping, keep what was measured
+            break
     th_pre, th_step = min(pre, key=pre.get), min(step, key=step.get)
     pre_full, step_full = pre[th_pre], step[th_step]
     del llm, o
-    torch.set_num_threads(default_threads)
     clip_s = t_cfg1 * (args.frames / 8.0) + pre_full + step_full * (args.new_tokens - 1)
+    probe = 0.0094 if args.llm == "7b" else 0.0146               # BASELINE.md 3 (8-core build container)
     return {"value": 1.0 / clip_s, "unit": "videos/sec", "cores": ncores, "kind": "reference",
             "kind_note": ("HF transformers " + transformers.__version__ + " CLIPVisionModel + LlamaForCausalLM.forward on the host cores: the modules the "
                           "reference's path executes (it has no arithmetic of its own beyond the numpy pooling, restated verbatim); the reference's glue "
                           "files cannot travel to the GPU box"),
-            "threads_tried": cand, "threads_used": {"vit": min(vit_times, key=vit_times.get), "prefill": th_pre, "decode_step": th_step},
+            "host_logical_cpus": os.cpu_count(),
+            "threads_tried": {"vit": sorted(vit_times), "prefill": sorted(pre), "decode_step": sorted(step)},
+            "threads_used": {"vit": min(vit_times, key=vit_times.get), "prefill": th_pre, "decode_step": th_step},
             "numa_nodes_interleaved": numa_nodes, "layers_timed": full_layers, "model_build_s": t_build,
-            "config1_8_frames_s": t_cfg1, "config1_by_threads_s": vit_times,
+            "config1_8_frames_s": t_cfg1, "config1_by_threads_s": {str(k): v for k, v in vit_times.items()},
             "prefill_s_full_depth": pre_full, "decode_step_s_full_depth": step_full, "prefill_by_threads_s": {str(k): v for k, v in pre.items()},
             "decode_step_by_threads_s": {str(k): v for k, v in step.items()},
             "decode_step_s_per_layer": step_full / full_layers, "decode_weight_stream_gbs": weight_bytes / step_full / 1e9,
-            "survey_probe_decode_step_s_per_layer": 0.0094 if args.llm == "7b" else 0.0146,     # BASELINE.md 3 (8-core build container)
+            "survey_probe_decode_step_s_per_layer": probe, "decode_per_layer_vs_survey_probe": step_full / full_layers / probe,
             "sample": (f"BASELINE config 1 in full (8 frames, 24-layer ViT-L/14 fp32 eager + numpy pool: {t_cfg1:.2f}s) scaled to {args.frames} frames; "
                        f"{args.llm.upper()}-shaped LlamaForCausalLM fp32 eager at FULL depth ({full_layers} layers, {weight_bytes / 1e9:.1f} GB of weights, "
-                       f"first-touch by the fill threads{', interleaved over %d NUMA nodes' % numa_nodes if numa_nodes else ''}): prefill S={S} {pre_full:.2f}s + {n_step} timed decode steps of {step_full * 1e3:.0f} ms "
+                       f"first-touch inside the affinity mask{', interleaved over %d NUMA nodes' % numa_nodes if numa_nodes else ''}): prefill S={S} {pre_full:.2f}s + {n_step} timed decode steps of {step_full * 1e3:.0f} ms "
                        f"({step_full / full_layers * 1e3:.1f} ms per layer, {weight_bytes / step_full / 1e9:.0f} GB/s) -> prefill + {args.new_tokens - 1} steps "
                        f"= {clip_s:.1f}s/clip; sample took {time.perf_counter() - t_all:.0f}s"),
             "seconds_per_clip": clip_s}
@@ -483,230 +540,112 @@ def main_dry(args):
         torch.distributed.destroy_process_group()
 
 
-def main():
-    args = parse()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        raise SystemExit(launch_self(args))
-    if args.dry:
-        return main_dry(args)
-    from video_llava_amd import _lib, parallel
-    from video_llava_amd import random_init as ri
-    from video_llava_amd.inference import get_spatio_temporal_features_torch
-    from video_llava_amd.model.video_chatgpt import VideoChatGPTConfig, VideoChatGPTLlamaForCausalLM, VisionConfig
-    from video_llava_amd.vision_tower import CLIPVisionTower, CLIPVisionTowerConfig
+class Workload:
+    """One configuration of the hot path on this rank's GPU: random-init tower + decoder of the named shapes, synthetic frames resident in HBM,
+    ActivityNet-QA-shaped prompts.  `a` carries dtype / llm / weights / image / workload / clips_per_gpu / frames / new_tokens."""
 
-    rank, world, local = parallel.init_distributed()
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    if os.environ.get("PGV_BENCH_SHARE_DEVICE"):        # control-flow smoke test of the N > 1 path on a 1-GPU box (with PGV_DIST_BACKEND=gloo)
-        local = 0
-    elif torch.cuda.device_count() < world:
-        raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} GPU(s) are visible (one rank per GPU; "
-                         "PGV_BENCH_SHARE_DEVICE=1 PGV_DIST_BACKEND=gloo runs the ranks on one device as a control-flow check)")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
-    ctx = _lib.Context.get(dev)
-    B, T, NEW = args.clips_per_gpu, args.frames, args.new_tokens
+    def __init__(self, a, dev, rank, world):
+        from video_llava_amd import _lib, parallel
+        from video_llava_amd import random_init as ri
+        from video_llava_amd.model.video_chatgpt import VideoChatGPTConfig, VideoChatGPTLlamaForCausalLM, VisionConfig
+        from video_llava_amd.vision_tower import CLIPVisionTower, CLIPVisionTowerConfig
+        self.a, self.dev, self.rank, self.world, self.parallel = a, dev, rank, world, parallel
+        self.dtype = dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float16
+        self.ctx = _lib.Context.get(dev)
+        self.B, self.T, self.NEW, self.S = a.clips_per_gpu, a.frames, a.new_tokens, a.image
+        S = self.S
+        self.video_rows = 100 + (S // 14) ** 2                      # 356 at 224 px, 676 at 336 px
+        self.projector = "linear" if S == 224 else "mlp2x_gelu"    # reference rule: model/video_chatgpt.py:52-55
+        self.tower = CLIPVisionTower(CLIPVisionTowerConfig(image_size=S), dtype, dev)
+        ri.load_streaming(self.tower, ri.iter_clip_tensors(image=S, device=dev, dtype=dtype, seed=1))
+        shapes = dict(hidden=4096, inter=11008, layers=32, heads=32) if a.llm == "7b" else dict(hidden=5120, inter=13824, layers=40, heads=40)
+        self.vocab = vocab = 32003
+        self.model = self.proj = None
+        if a.workload == "full":
+            cfg = VideoChatGPTConfig(vocab_size=vocab, hidden_size=shapes["hidden"], intermediate_size=shapes["inter"],
+                                     num_hidden_layers=shapes["layers"], num_attention_heads=shapes["heads"], eos_token_id=None,
+                                     mm_projector_type=self.projector)
+            self.model = VideoChatGPTLlamaForCausalLM(cfg, VisionConfig(frame_size=S), dtype, dev)
+            ri.load_streaming(self.model, ri.iter_llama_tensors(vocab=vocab, hidden=shapes["hidden"], inter=shapes["inter"], layers=shapes["layers"],
+                                                                projector=self.projector, device=dev, dtype=dtype, seed=2))
+            vc = self.model.get_model().vision_config
+            vc.vid_patch_token, vc.vid_start_token, vc.vid_end_token, vc.use_vid_start_end = vocab - 3, vocab - 2, vocab - 1, True
+            if a.weights == "fp8":
+                self.model.quantize_weights_fp8()
+        else:
+            from video_llava_amd.model.multimodal_projector.builder import HipLinear
+            self.proj = HipLinear(1024, 4096, dtype, dev)
+            self.proj.weight.data.normal_(0, 0.02); self.proj.bias.data.normal_(0, 0.02)
+        # ---- synthetic inputs resident in HBM ----
+        gen = torch.Generator(device=dev).manual_seed(100 + rank)
+        self.frames = torch.randint(0, 256, (self.B * self.T, S, S, 3), dtype=torch.uint8, device=dev, generator=gen)
+        self.n_global = self.B * world
+        prompts_all = make_prompts(self.n_global, vocab, self.video_rows, seed=5)
+        self.mine = parallel.shard_indices(self.n_global, rank, world)
+        self.prompts = [prompts_all[i] for i in self.mine]
+        self.vit_events = []
 
-    # ---- models (random init on the device) ----------------------------------------------------------
-    S = args.image
-    video_rows = 100 + (S // 14) ** 2                      # 356 at 224 px, 676 at 336 px
-    projector = "linear" if S == 224 else "mlp2x_gelu"   # reference rule: model/video_chatgpt.py:52-55
-    tower = CLIPVisionTower(CLIPVisionTowerConfig(image_size=S), dtype, dev)
-    ri.load_streaming(tower, ri.iter_clip_tensors(image=S, device=dev, dtype=dtype, seed=1))
-    shapes = dict(hidden=4096, inter=11008, layers=32, heads=32) if args.llm == "7b" else dict(hidden=5120, inter=13824, layers=40, heads=40)
-    vocab = 32003
-    model = None
-    if args.workload == "full":
-        cfg = VideoChatGPTConfig(vocab_size=vocab, hidden_size=shapes["hidden"], intermediate_size=shapes["inter"],
-                                 num_hidden_layers=shapes["layers"], num_attention_heads=shapes["heads"], eos_token_id=None,
-                                 mm_projector_type=projector)
-        model = VideoChatGPTLlamaForCausalLM(cfg, VisionConfig(frame_size=S), dtype, dev)
-        ri.load_streaming(model, ri.iter_llama_tensors(vocab=vocab, hidden=shapes["hidden"], inter=shapes["inter"], layers=shapes["layers"],
-                                                       projector=projector, device=dev, dtype=dtype, seed=2))
-        vc = model.get_model().vision_config
-        vc.vid_patch_token, vc.vid_start_token, vc.vid_end_token, vc.use_vid_start_end = vocab - 3, vocab - 2, vocab - 1, True
-        if args.weights == "fp8":
-            model.quantize_weights_fp8()
-    else:
-        from video_llava_amd.model.multimodal_projector.builder import HipLinear
-        proj = HipLinear(1024, 4096, dtype, dev)
-        proj.weight.data.normal_(0, 0.02); proj.bias.data.normal_(0, 0.02)
-
-    # ---- synthetic inputs resident in HBM ------------------------------------------------------------
-    gen = torch.Generator(device=dev).manual_seed(100 + rank)
-    frames = torch.randint(0, 256, (B * T, S, S, 3), dtype=torch.uint8, device=dev, generator=gen)
-    n_global = B * world
-    prompts_all = make_prompts(n_global, vocab, video_rows, seed=5)
-    mine = parallel.shard_indices(n_global, rank, world)
-    prompts = [prompts_all[i] for i in mine]
-
-    def vision(frames_u8):
-        px = ctx.preprocess_u8(frames_u8, dtype)
-        hid = tower(px, output_hidden_states=True).hidden_states[-2]
+    def vision(self, frames_u8):
+        from video_llava_amd.inference import get_spatio_temporal_features_torch
+        B, T = self.B, self.T
+        px = self.ctx.preprocess_u8(frames_u8, self.dtype)
+        hid = self.tower(px, output_hidden_states=True).hidden_states[-2]
         return torch.stack([get_spatio_temporal_features_torch(hid[b * T:(b + 1) * T, 1:]) for b in range(B)])   # [B, 356, 1024] fp16
 
-    vit_events = []
-
-    def step(new_tokens, collate=True, host_frames=None):
+    def step(self, new_tokens, collate=True, host_frames=None):
+        B, dev, prompts = self.B, self.dev, self.prompts
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()                                   # torch's current stream IS the stream libpgv launches on
-        pooled = vision(frames if host_frames is None else host_frames.to(dev, non_blocking=True))
+        pooled = self.vision(self.frames if host_frames is None else host_frames.to(dev, non_blocking=True))
         e1.record()
-        vit_events.append((e0, e1))
-        if args.workload == "vision":
-            return proj(pooled.to(dtype))
-        out = model.generate(prompts, video_spatio_temporal_features=pooled, do_sample=False, max_new_tokens=new_tokens,
-                             eos_token_id=None, chunk=64)
+        self.vit_events.append((e0, e1))
+        if self.a.workload == "vision":
+            return self.proj(pooled.to(self.dtype))
+        out = self.model.generate(prompts, video_spatio_temporal_features=pooled, do_sample=False, max_new_tokens=new_tokens,
+                                  eos_token_id=None, chunk=64)
         toks = torch.stack([out[b, len(prompts[b]):len(prompts[b]) + new_tokens] for b in range(B)]).to(torch.int32)
         lens = torch.full((B,), new_tokens, dtype=torch.int32, device=dev)
         if not collate:                               # rank-0-only profiled pass: no collective (the other ranks are not in it)
             return toks
-        return parallel.gather_answers(toks, lens, n_global, rank, world)
+        return self.parallel.gather_answers(toks, lens, self.n_global, self.rank, self.world)
 
-    def barrier():
-        if world > 1:
+    def barrier(self):
+        if self.world > 1:
             torch.distributed.barrier()
-        torch.cuda.synchronize(dev)
+        torch.cuda.synchronize(self.dev)
 
-    for _ in range(args.warmup):
-        step(NEW)
-    barrier()
-    vit_events.clear()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(NEW)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tt[0])
-    ms_per_step = elapsed / args.steps * 1e3
-    value = n_global * args.steps / elapsed
-    vit_ms = sum(a.elapsed_time(b) for a, b in vit_events) / max(len(vit_events), 1)      # frames -> pooled features, per step
-    overlap = None
-    if args.overlap_vision and args.workload == "full":
-        # Same K batches, every kernel still runs: the vision stage of batch i+1 is enqueued on a second stream (second pgv context = own
-        # workspace) before batch i's prefill + decode are enqueued on the main stream.  Decode is HBM-bound, the ViT is MFMA/power-bound.
-        ctx_v = _lib.Context(dev.index)
-        # decode runs on a pool stream too: the legacy default stream would synchronise with the (blocking) CU-masked stream
-        s_main = torch.cuda.Stream(dev)
-        s_main.wait_stream(torch.cuda.current_stream(dev))
-        if args.vision_cu_mask:
-            import ctypes
-            kind, n = args.vision_cu_mask.split(":"); n = int(n)
-            bits = list(range(n)) if kind == "first" else list(range(0, 256, 256 // n))
-            words = (ctypes.c_uint32 * 8)(*[sum(1 << (b % 32) for b in bits if b // 32 == wd) for wd in range(8)])
-            hip = ctypes.CDLL("libamdhip64.so")
-            raw = ctypes.c_void_p()
-            rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(raw), 8, words)
-            if rc != 0:
-                raise SystemExit(f"hipExtStreamCreateWithCUMask failed: {rc}")
-            s_vis = torch.cuda.ExternalStream(raw.value, device=dev)
-        else:
-            s_vis = torch.cuda.Stream(dev)
-
-        def vision_async():
-            s_vis.wait_stream(s_main)
-            tower.ctx = ctx_v
-            with torch.cuda.stream(s_vis):
-                pooled = vision(frames)
-                ev = torch.cuda.Event(); ev.record(s_vis)
-            tower.ctx = ctx
-            return pooled, ev
-
-        def run_overlapped(k):
-            nxt = vision_async()
-            for i in range(k):
-                pooled, ev = nxt
-                s_main.wait_event(ev)
-                pooled.record_stream(s_main)
-                nxt = vision_async() if i + 1 < k else None
-                with torch.cuda.stream(s_main):
-                    out = model.generate(prompts, video_spatio_temporal_features=pooled, do_sample=False, max_new_tokens=NEW, eos_token_id=None, chunk=64)
-                    toks = torch.stack([out[b, len(prompts[b]):len(prompts[b]) + NEW] for b in range(B)]).to(torch.int32)
-                    parallel.gather_answers(toks, torch.full((B,), NEW, dtype=torch.int32, device=dev), n_global, rank, world)
-
-        run_overlapped(1)
-        barrier()
-        tv = time.perf_counter()
-        vision_async(); barrier()
-        vis_alone_ms = (time.perf_counter() - tv) * 1e3
-        t1 = time.perf_counter()
-        run_overlapped(args.steps)
-        barrier()
-        el = time.perf_counter() - t1
-        if world > 1:
-            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+    def max_over_ranks(self, seconds):
+        if self.world > 1:
+            tt = torch.tensor([seconds], dtype=torch.float64, device=self.dev)
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-            el = float(tt[0])
-        overlap = {"value": n_global * args.steps / el, "unit": "videos/sec", "ms_per_step": el / args.steps * 1e3,
-                   "vision_alone_on_its_stream_ms": vis_alone_ms, "vision_cu_mask": args.vision_cu_mask or None}
-    pcie = None
-    if not args.no_host_frames:                              # same steps, frames handed over as host buffers (the reference's boundary: PIL images on the host)
-        host = frames.cpu().pin_memory()
-        step(NEW, host_frames=host)
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step(NEW, host_frames=host)
-        barrier()
-        el = time.perf_counter() - t1
-        if world > 1:
-            tt = torch.tensor([el], dtype=torch.float64, device=dev)
-            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-            el = float(tt[0])
-        pcie = {"value": n_global * args.steps / el, "unit": "videos/sec", "ms_per_step": el / args.steps * 1e3,
-                "h2d_bytes_per_step_per_gpu": int(host.numel())}
-    latency = None
-    if not args.no_latency and args.workload == "full" and rank == 0:
-        # BASELINE configs[2] as written: ONE synthetic 100-frame clip, batch 1, frames -> 256 greedy tokens (host-visible latency incl. the final D2H)
-        def one_clip():
-            px = ctx.preprocess_u8(frames[:T], dtype)
-            hid = tower(px, output_hidden_states=True).hidden_states[-2]
-            pooled1 = get_spatio_temporal_features_torch(hid[:, 1:])[None]
-            out = model.generate([prompts[0]], video_spatio_temporal_features=pooled1, do_sample=False, max_new_tokens=NEW, eos_token_id=None, chunk=64)
-            return out.cpu()
-        one_clip()
-        torch.cuda.synchronize(dev)
-        ts = []
-        for _ in range(3):
-            t1 = time.perf_counter(); one_clip(); ts.append(time.perf_counter() - t1)
-        latency = {"clips": 1, "frames": T, "new_tokens": NEW, "seconds_median": sorted(ts)[1], "seconds_min": min(ts),
-                   "videos_per_sec_batch1": 1.0 / sorted(ts)[1]}
-    runner = None
-    if not args.no_runner and args.workload == "full" and world == 1:
-        try:
-            runner = runner_measurement(args, model, tower, video_rows, S, rank, world)
-            runner["ratio_to_value"] = runner["videos_per_sec"] / value
-        except Exception as e:                                   # noqa: BLE001 -- a side field (needs ~250 MB of local disk) never costs the headline line
-            runner = {"videos_per_sec": None, "error": f"{type(e).__name__}: {e}"}
-    if world > 1:
-        torch.distributed.barrier()
-    clip_feat_tflops = B * T * VIT_FLOP_PER_FRAME_23L[S] / (vit_ms * 1e-3) / 1e12
-    clip_feat_tflops_total = clip_feat_tflops                 # sum over ranks of each rank's own stage rate
-    if world > 1:
-        tt = torch.tensor([clip_feat_tflops], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.SUM)
-        clip_feat_tflops_total = float(tt[0])
+            return float(tt[0])
+        return seconds
 
-    # ---- the one exchange step, timed alone (N > 1): all-gather of the answer buffer ---------------------------------
-    collective = None
-    if world > 1 and args.workload == "full":
-        toks_c = torch.stack([torch.tensor(dry_pattern(i, NEW, vocab), dtype=torch.int32) for i in mine]).to(dev)
-        lens_c = torch.full((B,), NEW, dtype=torch.int32, device=dev)
-        collective, ans_c = time_collective(parallel, toks_c, lens_c, n_global, rank, world, barrier)
-        assert all(ans_c[i] == dry_pattern(i, NEW, vocab) for i in range(n_global)), f"rank {rank}: collation mismatch"
+    def timed(self, steps, warmup, host_frames=None):
+        """W untimed steps, then exactly K steps bracketed by barrier + synchronize on both sides; MAX over ranks.  Returns (seconds, per-rank
+        per-step list of seconds is not kept), the ViT-stage ms per step from events on the launch stream."""
+        for _ in range(warmup):
+            self.step(self.NEW, host_frames=host_frames)
+        self.barrier()
+        self.vit_events.clear()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step(self.NEW, host_frames=host_frames)
+        self.barrier()
+        own = time.perf_counter() - t0
+        elapsed = self.max_over_ranks(own)
+        vit_ms = sum(x.elapsed_time(y) for x, y in self.vit_events) / max(len(self.vit_events), 1)      # frames -> pooled features, per step
+        return elapsed, vit_ms, own
 
-    # ---- profiled pass: hipEvent pairs around every launch of each kernel family, on the launch stream -----------------
-    fam = {}
-    roofline = None
-    if rank == 0 and not args.no_profile_pass:
+    def clip_tflops(self, vit_ms):
+        return self.B * self.T * VIT_FLOP_PER_FRAME_23L[self.S] / (vit_ms * 1e-3) / 1e12
+
+    def profile_pass(self, ms_per_step):
+        """hipEvent pairs around every launch of each kernel family, on the launch stream -> (families, roofline of the dominant one)."""
+        a, ctx, dev, NEW = self.a, self.ctx, self.dev, self.NEW
         prof_tokens = min(NEW, 9)
         ctx.prof_enable(True); ctx.prof_reset()
-        step(prof_tokens, collate=False)
+        self.step(prof_tokens, collate=False)
         torch.cuda.synchronize(dev)
         raw = ctx.prof_get()
         ctx.prof_enable(False)
@@ -716,9 +655,10 @@ def main():
         # (sum of the pairs - graph time) / launches is removed from every per-launch average below, so the corrected decode families add up
         # to the decode time of the timed region.  An empty pair costs ~4.7 us here.
         ev_us, cal = 0.5 * pair_ms * 1e3, None
-        if args.workload == "full":
+        if a.workload == "full":
             CAL = 8
-            pooled = vision(frames)
+            model, prompts = self.model, self.prompts
+            pooled = self.vision(self.frames)
             kv, nxt, _ = model.prefill(prompts, pooled, max(len(p) for p in prompts) + 4 * CAL + 8)
             model.decode_greedy(kv, nxt, CAL)                                   # warm: first call is eager, second captures the graph
             model.decode_greedy(kv, nxt, CAL)
@@ -733,7 +673,9 @@ def main():
             n_l, paired_ms = sum(d["launches"] for d in dec), sum(d["ms"] for d in dec)
             ev_us = min(max((paired_ms - graph_ms) / n_l * 1e3, 0.0), pair_ms * 1e3)
             cal = {"tokens": CAL, "launches": n_l, "graph_replay_ms": graph_ms, "sum_of_pairs_ms": paired_ms, "empty_pair_us": pair_ms * 1e3}
+            del kv
         decode_scale = (NEW - 1) / max(prof_tokens - 1, 1)
+        fam = {}
         for name, r in raw.items():
             if r["launches"] == 0:
                 continue
@@ -760,7 +702,187 @@ def main():
         roofline["event_calibration"] = cal
         roofline["share_of_step"] = d["ms_per_step_est"] / ms_per_step
         roofline["algorithmic_bytes_per_launch"] = raw[dom]["bytes"] / raw[dom]["launches"] if raw[dom]["bytes"] > 0 else None
-        roofline.update(pmc_traffic(dom, "traffic" if (args.llm == "7b" and args.weights == "16bit" and args.image == 224) else f"{args.llm}_{args.weights}"))
+        roofline.update(pmc_traffic(dom, "traffic" if (a.llm == "7b" and a.weights == "16bit" and a.image == 224) else f"{a.llm}_{a.weights}"))
+        return fam, roofline
+
+    def free(self):
+        self.model = self.tower = self.proj = self.frames = None
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+
+
+def side_line(args, dev, overrides, steps, warmup, with_roofline=False):
+    """A guarded side measurement of the default run: the same timed loop on another configuration (own models, freed afterwards)."""
+    import copy
+    a = copy.copy(args)
+    for k, v in overrides.items():
+        setattr(a, k, v)
+    t0 = time.perf_counter()
+    w = Workload(a, dev, 0, 1)
+    try:
+        t_build = time.perf_counter() - t0
+        elapsed, vit_ms, _ = w.timed(steps, warmup)
+        ms = elapsed / steps * 1e3
+        out = {"value": w.n_global * steps / elapsed, "unit": "videos/sec", "ms_per_step": ms, "steps": steps, "warmup": warmup, "dtype": a.dtype, "llm": a.llm,
+               "llm_weights": a.weights, "clips_per_gpu_per_step": a.clips_per_gpu, "new_tokens": a.new_tokens,
+               "clip_feat_ms_per_step": vit_ms, "clip_feat_frac": w.clip_tflops(vit_ms) / PEAK_MFMA_TFLOPS, "model_build_s": t_build}
+        if with_roofline:
+            fam, roof = w.profile_pass(ms)
+            out["roofline"] = roof
+            out["family_avg_us"] = {k: v["avg_us"] for k, v in fam.items()}
+        return out
+    finally:
+        w.free()
+
+
+def main():
+    args = parse()
+    if args.cpu_baseline_child:
+        print(json.dumps(cpu_baseline_child(args)), flush=True)
+        return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_self(args))
+    if args.dry:
+        return main_dry(args)
+    from video_llava_amd import _lib, parallel
+    from video_llava_amd.inference import get_spatio_temporal_features_torch
+
+    rank, world, local = parallel.init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if os.environ.get("PGV_BENCH_SHARE_DEVICE"):        # control-flow smoke test of the N > 1 path on a 1-GPU box (with PGV_DIST_BACKEND=gloo)
+        local = 0
+    elif torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} GPU(s) are visible (one rank per GPU; "
+                         "PGV_BENCH_SHARE_DEVICE=1 PGV_DIST_BACKEND=gloo runs the ranks on one device as a control-flow check)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    parallel.pin_rank_to_numa_node(local)                 # host threads of this rank (prefetch, OMP) next to its GPU; silent when sysfs says nothing
+    wl = Workload(args, dev, rank, world)
+    ctx, model, tower, frames, prompts = wl.ctx, wl.model, wl.tower, wl.frames, wl.prompts
+    B, T, NEW, S, vocab, n_global, mine = wl.B, wl.T, wl.NEW, wl.S, wl.vocab, wl.n_global, wl.mine
+    dtype, video_rows, projector = wl.dtype, wl.video_rows, wl.projector
+    vision, step, barrier = wl.vision, wl.step, wl.barrier
+
+    elapsed, vit_ms, own_elapsed = wl.timed(args.steps, args.warmup)
+    ms_per_step = elapsed / args.steps * 1e3
+    value = n_global * args.steps / elapsed
+    rank_ms = None
+    if world > 1:                                             # every rank's own ms per step: a straggler shows in the one JSON line
+        tt = torch.zeros(world, dtype=torch.float64, device=dev)
+        tt[rank] = own_elapsed / args.steps * 1e3
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.SUM)
+        rank_ms = [float(x) for x in tt.cpu()]
+    overlap = None
+    if args.overlap_vision and args.workload == "full":
+        # Same K batches, every kernel still runs: the vision stage of batch i+1 is enqueued on a second stream (second pgv context = own
+        # workspace) before batch i's prefill + decode are enqueued on the main stream.  Decode is HBM-bound, the ViT is MFMA/power-bound.
+        ctx_v = _lib.Context(dev.index)
+        # decode runs on a pool stream too: the legacy default stream would synchronise with the (blocking) CU-masked stream
+        s_main = torch.cuda.Stream(dev)
+        s_main.wait_stream(torch.cuda.current_stream(dev))
+        if args.vision_cu_mask:
+            import ctypes
+            kind, n = args.vision_cu_mask.split(":"); n = int(n)
+            bits = list(range(n)) if kind == "first" else list(range(0, 256, 256 // n))
+            words = (ctypes.c_uint32 * 8)(*[sum(1 << (b % 32) for b in bits if b // 32 == wd) for wd in range(8)])
+            hip = ctypes.CDLL("libamdhip64.so")
+            raw = ctypes.c_void_p()
+            rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(raw), 8, words)
+            if rc != 0:
+                raise SystemExit(f"hipExtStreamCreateWithCUMask failed: {rc}")
+            s_vis = torch.cuda.ExternalStream(raw.value, device=dev)
+        else:
+            s_vis = torch.cuda.Stream(dev)
+
+        def vision_async():
+            s_vis.wait_stream(s_main)
+            tower.ctx = wl.ctx = ctx_v
+            with torch.cuda.stream(s_vis):
+                pooled = vision(frames)
+                ev = torch.cuda.Event(); ev.record(s_vis)
+            tower.ctx = wl.ctx = ctx
+            return pooled, ev
+
+        def run_overlapped(k):
+            nxt = vision_async()
+            for i in range(k):
+                pooled, ev = nxt
+                s_main.wait_event(ev)
+                pooled.record_stream(s_main)
+                nxt = vision_async() if i + 1 < k else None
+                with torch.cuda.stream(s_main):
+                    out = model.generate(prompts, video_spatio_temporal_features=pooled, do_sample=False, max_new_tokens=NEW, eos_token_id=None, chunk=64)
+                    toks = torch.stack([out[b, len(prompts[b]):len(prompts[b]) + NEW] for b in range(B)]).to(torch.int32)
+                    parallel.gather_answers(toks, torch.full((B,), NEW, dtype=torch.int32, device=dev), n_global, rank, world)
+
+        run_overlapped(1)
+        barrier()
+        tv = time.perf_counter()
+        vision_async(); barrier()
+        vis_alone_ms = (time.perf_counter() - tv) * 1e3
+        t1 = time.perf_counter()
+        run_overlapped(args.steps)
+        barrier()
+        el = wl.max_over_ranks(time.perf_counter() - t1)
+        overlap = {"value": n_global * args.steps / el, "unit": "videos/sec", "ms_per_step": el / args.steps * 1e3,
+                   "vision_alone_on_its_stream_ms": vis_alone_ms, "vision_cu_mask": args.vision_cu_mask or None}
+    pcie = None
+    if not args.no_host_frames:                              # same steps, frames handed over as host buffers (the reference's boundary: PIL images on the host)
+        host = frames.cpu().pin_memory()
+        keep = list(wl.vit_events)
+        el, _, _ = wl.timed(args.steps, 1, host_frames=host)
+        wl.vit_events[:] = keep
+        pcie = {"value": n_global * args.steps / el, "unit": "videos/sec", "ms_per_step": el / args.steps * 1e3,
+                "h2d_bytes_per_step_per_gpu": int(host.numel())}
+        del host
+    latency = None
+    if not args.no_latency and args.workload == "full" and rank == 0:
+        # BASELINE configs[2] as written: ONE synthetic 100-frame clip, batch 1, frames -> 256 greedy tokens (host-visible latency incl. the final D2H)
+        def one_clip():
+            px = ctx.preprocess_u8(frames[:T], dtype)
+            hid = tower(px, output_hidden_states=True).hidden_states[-2]
+            pooled1 = get_spatio_temporal_features_torch(hid[:, 1:])[None]
+            out = model.generate([prompts[0]], video_spatio_temporal_features=pooled1, do_sample=False, max_new_tokens=NEW, eos_token_id=None, chunk=64)
+            return out.cpu()
+        one_clip()
+        torch.cuda.synchronize(dev)
+        ts = []
+        for _ in range(3):
+            t1 = time.perf_counter(); one_clip(); ts.append(time.perf_counter() - t1)
+        latency = {"clips": 1, "frames": T, "new_tokens": NEW, "seconds_median": sorted(ts)[1], "seconds_min": min(ts),
+                   "videos_per_sec_batch1": 1.0 / sorted(ts)[1]}
+    runner = None
+    if not args.no_runner and args.workload == "full" and world == 1:
+        try:
+            runner = runner_measurement(args, model, tower, video_rows, S, rank, world)
+            runner["ratio_to_value"] = runner["videos_per_sec"] / value
+        except Exception as e:                                   # noqa: BLE001 -- a side field (needs ~250 MB of local disk) never costs the headline line
+            runner = {"videos_per_sec": None, "error": f"{type(e).__name__}: {e}"}
+    if world > 1:
+        torch.distributed.barrier()
+    clip_feat_tflops = wl.clip_tflops(vit_ms)
+    clip_feat_tflops_total = clip_feat_tflops                 # sum over ranks of each rank's own stage rate
+    if world > 1:
+        tt = torch.tensor([clip_feat_tflops], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.SUM)
+        clip_feat_tflops_total = float(tt[0])
+
+    # ---- the one exchange step, timed alone (N > 1): all-gather of the answer buffer ---------------------------------
+    collective = None
+    if world > 1 and args.workload == "full":
+        toks_c = torch.stack([torch.tensor(dry_pattern(i, NEW, vocab), dtype=torch.int32) for i in mine]).to(dev)
+        lens_c = torch.full((B,), NEW, dtype=torch.int32, device=dev)
+        collective, ans_c = time_collective(parallel, toks_c, lens_c, n_global, rank, world, barrier)
+        assert all(ans_c[i] == dry_pattern(i, NEW, vocab) for i in range(n_global)), f"rank {rank}: collation mismatch"
+        collective["rank_ms_per_step"] = rank_ms
+        collective["rank_ms_per_step_min_max"] = [min(rank_ms), max(rank_ms)]
+
+    # ---- profiled pass: hipEvent pairs around every launch of each kernel family, on the launch stream -----------------
+    fam, roofline = {}, None
+    if rank == 0 and not args.no_profile_pass:
+        fam, roofline = wl.profile_pass(ms_per_step)
 
     if rank == 0:
         line = {
@@ -795,6 +917,22 @@ def main():
             line["family_share_of_step"] = {k: v["ms_per_step_est"] / ms_per_step for k, v in fam.items()}
         if roofline:
             line["roofline"] = roofline
+        headline = (args.workload == "full" and args.llm == "7b" and args.weights == "16bit" and args.dtype == "bf16" and S == 224 and world == 1)
+        if headline and not args.no_side:
+            # Guarded side lines: driver-timed numbers for the parity-grade dtype and for BASELINE configs[4]; a failure costs
+            # only its own field.  The headline models are freed first.
+            wl.free()
+            del model, tower, frames
+            side = {}
+            for key, ov, st, wu, roof in (("fp16", {"dtype": "fp16"}, 5, 1, False),
+                                          ("cfg5_13b_fp8", {"llm": "13b", "weights": "fp8"}, 3, 1, True)):
+                try:
+                    side[key] = side_line(args, dev, ov, st, wu, roof)
+                except Exception as e:                           # noqa: BLE001
+                    side[key] = {"value": None, "error": f"{type(e).__name__}: {e}"}
+            if side["fp16"].get("value"):
+                side["fp16"]["ratio_to_headline"] = side["fp16"]["value"] / value
+            line["side"] = side
         if args.gpus == 1 and not args.no_cpu_baseline and args.workload == "full":
             try:
                 line["cpu_baseline"] = cpu_baseline_reference(args)

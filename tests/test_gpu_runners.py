@@ -225,3 +225,136 @@ def test_video_features_batch_equals_per_clip(ctx):
     for c, got in zip(clips, together):
         alone = video_features(c, tower, IP())
         assert got.shape == alone.shape == (100 + ccfg.patches, 1024) and torch.equal(got, alone)
+
+
+# --------------------------------------------------------------------------------------------------
+# round 4: runner details
+# --------------------------------------------------------------------------------------------------
+def _tiny_components(seed_c=21, seed_l=22, max_pos=2048):
+    from video_llava_amd.model.video_chatgpt import VideoChatGPTConfig, VideoChatGPTLlamaForCausalLM, VisionConfig
+    ccfg, lcfg = synth.CLIP_TINY, synth.LLAMA_TINY
+    cw = synth.make_clip_weights(ccfg, seed=seed_c)
+    lw = synth.make_llama_weights(lcfg, seed=seed_l, head_std=0.08)
+    tower = _tower(ccfg, cw)
+    model = VideoChatGPTLlamaForCausalLM(VideoChatGPTConfig(vocab_size=lcfg.vocab, hidden_size=lcfg.hidden, intermediate_size=lcfg.inter,
+                                                            num_hidden_layers=lcfg.layers, num_attention_heads=lcfg.heads, eos_token_id=None,
+                                                            max_position_embeddings=max_pos),
+                                         VisionConfig(frame_size=ccfg.image), torch.float16)
+    model.load_state_dict(lw)
+    vc = model.get_model().vision_config
+    vc.vid_patch_token, vc.vid_start_token, vc.vid_end_token, vc.use_vid_start_end = lcfg.vocab - 3, lcfg.vocab - 2, lcfg.vocab - 1, True
+
+    class IP:
+        crop_size = {"height": ccfg.image, "width": ccfg.image}
+    return ccfg, lcfg, cw, lw, tower, model, IP(), 100 + (ccfg.image // ccfg.patch) ** 2
+
+
+class _StopTok(_Tok):
+    """The synthetic tokenizer with chosen ids decoding to the text of a stop string ("###" is ordinary text for video-chatgpt_v1: it is
+    NOT a single-id keyword, so only the decoded-tail branch of KeywordsStoppingCriteria can see it)."""
+
+    def __init__(self, vocab, stop_ids):
+        super().__init__(vocab)
+        self.stop_ids = set(stop_ids)
+
+    def batch_decode(self, ids, skip_special_tokens=True):
+        return [" ".join("###" if int(t) in self.stop_ids else str(int(t)) for t in row) for row in ids]
+
+
+def test_batched_runner_stops_on_a_text_stop_string(ctx, tmp_path):
+    """conv mode video-chatgpt_v1 (stop string "###", not EOS) with the default-sized token budget: the batched greedy path must stop a group
+    within ONE chunk of the last sequence's stop string instead of decoding max_new_tokens steps, and every prediction must equal the
+    per-sample path (video_chatgpt_infer with the reference's KeywordsStoppingCriteria, reference inference.py:101-102, model/utils.py:6-26)."""
+    from video_llava_amd.eval import run_inference_qa_activitynet as qa
+    from video_llava_amd.inference import build_prompt, video_chatgpt_infer
+    ccfg, lcfg, cw, lw, tower, model, ip, V = _tiny_components()
+    vd = tmp_path / "v"; vd.mkdir()
+    names = ["s1", "s2", "s3"]
+    frames = {n: synth.make_frames(5 + i, ccfg.image, seed=60 + i) for i, n in enumerate(names)}
+    for n in names:
+        np.save(vd / f"v_{n}.npy", frames[n])
+    qs = [{"video_name": n, "question": f"what happens {i}?", "question_id": f"{n}_q"} for i, n in enumerate(names)]
+    (tmp_path / "q.json").write_text(json.dumps(qs)); (tmp_path / "a.json").write_text(json.dumps([{"answer": "a"}] * 3))
+    # free-running greedy ids of every sample (plain tokenizer, no stop): choose as "stop ids" the token each sample emits at step 5 / 9 / 40
+    plain = _Tok(lcfg.vocab)
+    runs = {}
+    for n, q in zip(names, qs):
+        prompt, _ = build_prompt(q["question"], "video-chatgpt_v1", V, True)
+        ids = plain([prompt]).input_ids[0]
+        pooled = ovis.spatio_temporal_pool_torch(ovis.clip_select_features(ovis.clip_preprocess(frames[n]), cw, ccfg))
+        out = model.generate([ids], video_spatio_temporal_features=pooled.half().to(DEV)[None], do_sample=False, max_new_tokens=64)
+        runs[n] = out[0, len(ids):].tolist()
+    stop_ids = {runs["s1"][5], runs["s2"][9], runs["s3"][40]}
+    tok = _StopTok(lcfg.vocab, stop_ids)
+    last_stop = max(next(i for i, t in enumerate(runs[n]) if t in stop_ids) for n in names) + 1        # tokens until the LAST sequence has stopped
+    assert last_stop <= 41
+    steps = {"n": 0}
+    orig = type(model).decode_greedy
+
+    def counting(self, kv, first, n, eos_id=-1):
+        steps["n"] += n
+        return orig(self, kv, first, n, eos_id)
+    type(model).decode_greedy = counting
+    try:
+        args = qa.parse_args(["--video_dir", str(vd), "--gt_file_question", str(tmp_path / "q.json"), "--gt_file_answers", str(tmp_path / "a.json"),
+                              "--output_dir", str(tmp_path / "out"), "--output_name", "p", "--model-name", "x", "--projection_path", "y",
+                              "--conv-mode", "video-chatgpt_v1", "--batch", "3", "--max_new_tokens", "1024", "--timings", str(tmp_path / "t.jsonl")])
+        out = qa.run_inference(args, components=(model, tower, tok, ip, V))
+    finally:
+        type(model).decode_greedy = orig
+    assert [o["id"] for o in out] == ["s1_q", "s2_q", "s3_q"]
+    assert steps["n"] + 1 <= last_stop + 32, f"{steps['n']} decode steps for a group whose last stop string ends at token {last_stop}"
+    for o, n in zip(out, names):
+        ref = video_chatgpt_infer(frames[n], o["question"], "video-chatgpt_v1", model, tower, tok, ip, V, do_sample=False, max_new_tokens=1024)
+        assert o["pred"] == ref and "###" not in o["pred"], (n, o["pred"], ref)
+        assert len(o["pred"].split()) < 45
+    # --timings: one JSON line per task with the stage times of its group
+    lines = [json.loads(x) for x in open(tmp_path / "t.jsonl")]
+    assert [x["task"] for x in lines] == [0, 1, 2] and all(x["ok"] and x["group_size"] == 3 and not x["feature_cache_hit"] for x in lines)
+    assert all(x["tower_pool_s_group"] > 0 and x["prefill_s_group"] > 0 and x["decode_s_group"] > 0 and x["load_s"] > 0 for x in lines)
+    assert lines[0]["tokens"] == 6 + 1 - 1 or lines[0]["tokens"] >= 2
+
+
+def test_runner_feature_cache_and_sampling_collation(ctx, tmp_path):
+    """(a) Several questions about the same videos in different groups: the tower runs once per DISTINCT clip (LRU of pooled features across
+    groups), and the predictions equal a run with the cache disabled.  (b) --do_sample goes through the same fixed-shape id collation as the
+    greedy path and reproduces video_chatgpt_infer's text for the same generator state."""
+    from video_llava_amd.eval import run_inference_qa_activitynet as qa
+    from video_llava_amd.inference import video_chatgpt_infer
+    ccfg, lcfg, cw, lw, tower, model, ip, V = _tiny_components()
+    tok = _Tok(lcfg.vocab)
+    vd = tmp_path / "v"; vd.mkdir()
+    for i, n in enumerate(["a", "b"]):
+        np.save(vd / f"v_{n}.npy", synth.make_frames(6 + i, ccfg.image, seed=70 + i))
+    order = ["a", "b", "a", "b", "a", "a"]
+    qs = [{"video_name": n, "question": f"question number {i}?", "question_id": f"q{i}"} for i, n in enumerate(order)]
+    (tmp_path / "q.json").write_text(json.dumps(qs)); (tmp_path / "a.json").write_text(json.dumps([{"answer": "x"}] * len(qs)))
+    base = ["--video_dir", str(vd), "--gt_file_question", str(tmp_path / "q.json"), "--gt_file_answers", str(tmp_path / "a.json"),
+            "--output_dir", str(tmp_path / "out"), "--model-name", "x", "--projection_path", "y", "--batch", "2", "--max_new_tokens", "5"]
+    frames_seen = {"n": 0, "calls": 0}
+    orig_call = type(tower).__call__
+
+    def counting_call(self, px, *a, **k):
+        frames_seen["n"] += int(px.shape[0]); frames_seen["calls"] += 1
+        return orig_call(self, px, *a, **k)
+    type(tower).__call__ = counting_call
+    try:
+        with_cache = qa.run_inference(qa.parse_args(base + ["--output_name", "c1"]), components=(model, tower, tok, ip, V))
+        assert frames_seen == {"n": 6 + 7, "calls": 1}, frames_seen           # group 0 holds both clips; groups 1 and 2 hit the cache
+        frames_seen.update(n=0, calls=0)
+        without = qa.run_inference(qa.parse_args(base + ["--output_name", "c0", "--feature-cache", "0"]), components=(model, tower, tok, ip, V))
+        assert frames_seen == {"n": 3 * 13 - 7, "calls": 3}, frames_seen      # groups (a, b), (a, b), (a, a): one pass each over the distinct clips
+    finally:
+        type(tower).__call__ = orig_call
+    assert with_cache == without and len(with_cache) == 6
+    # (b) sampling
+    one = [qs[1]]
+    (tmp_path / "q1.json").write_text(json.dumps(one)); (tmp_path / "a1.json").write_text(json.dumps([{"answer": "x"}]))
+    sargs = qa.parse_args(["--video_dir", str(vd), "--gt_file_question", str(tmp_path / "q1.json"), "--gt_file_answers", str(tmp_path / "a1.json"),
+                           "--output_dir", str(tmp_path / "out"), "--output_name", "s", "--model-name", "x", "--projection_path", "y", "--max_new_tokens", "12",
+                           "--do_sample"])
+    torch.manual_seed(1234)
+    got = qa.run_inference(sargs, components=(model, tower, tok, ip, V))
+    torch.manual_seed(1234)
+    ref = video_chatgpt_infer(np.load(vd / "v_b.npy"), one[0]["question"], "pg-video-llava", model, tower, tok, ip, V, max_new_tokens=12)
+    assert len(got) == 1 and got[0]["pred"] == ref and len(ref.split()) == 12

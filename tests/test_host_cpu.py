@@ -5,6 +5,7 @@ import os
 import re
 import socket
 import subprocess
+import time
 import sys
 
 import numpy as np
@@ -151,6 +152,97 @@ torch.distributed.destroy_process_group()
     want = [[100 * i + t for t in range(6 - (i % 3))] for i in range(5)]
     want[3] = []                                                        # failed clip keeps an empty slot
     assert ans == want
+
+
+def _spawn_ranks(script, world, extra_env=None, timeout=180):
+    """Start `world` plain processes (no elastic agent: a dying rank must be noticed by OUR code, not by torchrun killing the group)."""
+    port = _free_port()
+    procs = []
+    for rk in range(world):
+        env = dict(os.environ, RANK=str(rk), LOCAL_RANK=str(rk), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **(extra_env or {}))
+        procs.append(subprocess.Popen([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env))
+    outs = []
+    for pr in procs:
+        try:
+            out, _ = pr.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            out, _ = pr.communicate()
+            out += "\n<<HUNG: killed by the test>>"
+        outs.append((pr.returncode, out))
+    return outs
+
+
+def test_dp_rank_raising_mid_shard_keeps_its_slots_failed(tmp_path):
+    """one rank's infer raises from its second group on (a GPU fault mid-shard): every rank must still finish, with exactly
+    that rank's later slots marked failed (None: distinct from an empty answer) -- the skip-bad-clip policy of the reference's runner
+    (video_chatgpt/eval/run_inference_qa_activitynet.py:74,103-104) applied per group."""
+    script = tmp_path / "raise.py"
+    script.write_text(f'''
+import sys, json, torch
+sys.path.insert(0, {ROOT!r})
+from video_llava_amd import parallel
+rank, world, local = parallel.init_distributed("gloo", timeout_s=60)
+N, NEW = 12, 4
+calls = [0]
+def infer(group):
+    calls[0] += 1
+    if rank == 1 and calls[0] >= 2: raise RuntimeError("device fault on rank 1")
+    return torch.stack([torch.arange(NEW, dtype=torch.int32) + 10 * i for i in group]), [NEW + 1 for i in group]
+ans = parallel.run_sharded(N, infer, NEW, rank, world, torch.device("cpu"), per_gpu_batch=2, length_offset=1)
+open({str(tmp_path)!r} + f"/r_{{rank}}.json", "w").write(json.dumps(ans))
+torch.distributed.destroy_process_group()
+''')
+    outs = _spawn_ranks(script, 2)
+    assert all(rc == 0 for rc, _ in outs), outs
+    a0, a1 = (json.load(open(tmp_path / f"r_{rk}.json")) for rk in (0, 1))
+    assert a0 == a1
+    want = [[10 * i + t for t in range(4)] for i in range(12)]
+    for i in (8, 9, 10, 11):                       # rank 1 owns clips 6..11; its first group (6, 7) succeeded
+        want[i] = None
+    assert a0 == want
+
+
+def test_dp_rank_exiting_fails_the_survivor_loudly_not_forever(tmp_path):
+    """A rank that EXITS before the collation (killed, out of memory): the survivor must not hang in the all-gather -- it raises
+    parallel.CollationError well inside the process-group timeout (here 20 s) and exits non-zero."""
+    script = tmp_path / "exit.py"
+    script.write_text(f'''
+import os, sys, time, torch
+sys.path.insert(0, {ROOT!r})
+from video_llava_amd import parallel
+rank, world, local = parallel.init_distributed("gloo", timeout_s=20)
+def infer(group):
+    if rank == 1: os._exit(7)
+    return torch.zeros(len(group), 3, dtype=torch.int32), [3] * len(group)
+t0 = time.time()
+try:
+    parallel.run_sharded(4, infer, 3, rank, world, torch.device("cpu"), per_gpu_batch=2)
+except parallel.CollationError as e:
+    print("LOUD after %.1f s:" % (time.time() - t0), e); sys.exit(5)
+print("collated?!"); sys.exit(0)
+''')
+    t0 = time.time()
+    outs = _spawn_ranks(script, 2, timeout=150)
+    assert outs[1][0] == 7
+    assert outs[0][0] == 5 and "LOUD" in outs[0][1] and "HUNG" not in outs[0][1], outs[0]
+    assert time.time() - t0 < 120
+
+
+def test_rank_affinity_slices_and_silent_fallback():
+    """Per-rank CPU placement (parallel.pin_rank_to_numa_node): the slices of a node's CPU list are disjoint, contiguous and cover it; with
+    no GPU / no sysfs entry the call changes nothing and returns None."""
+    from video_llava_amd import parallel
+    cpus = list(range(64, 128)) + list(range(192, 256))
+    parts = [parallel.affinity_slice(cpus, 4, i) for i in range(4)]
+    assert sum(parts, []) == cpus and [len(x) for x in parts] == [32, 32, 32, 32]
+    parts = [parallel.affinity_slice(list(range(10)), 3, i) for i in range(3)]
+    assert sum(parts, []) == list(range(10)) and [len(x) for x in parts] == [4, 3, 3]
+    assert parallel.affinity_slice([1, 2], 4, 3) == [1, 2]                      # fewer CPUs than ranks: share them
+    assert parallel._parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    before = os.sched_getaffinity(0)
+    assert parallel.pin_rank_to_numa_node(0, 1) is None                          # no GPU in the build container
+    assert os.sched_getaffinity(0) == before
 
 
 @pytest.mark.parametrize("launcher", ["self", "torchrun"])

@@ -24,6 +24,12 @@ def add_runtime_arguments(parser):
                         help=f"clips answered together per GPU (greedy decoding; the decode kernels tile at most {MAX_BATCH} sequences)")
     parser.add_argument("--max_new_tokens", type=int, default=1024)
     parser.add_argument("--do_sample", action="store_true", help="reference decoding: temperature-0.2 sampling, one clip at a time")
+    parser.add_argument("--timings", default=None, metavar="OUT.jsonl",
+                        help="append one JSON line per answered task (rank-local file `OUT.jsonl.rank<r>` when world > 1): frame load, upload + ingest, "
+                             "tower + pool, prefill, decode seconds, generated tokens, group size, feature-cache hit (SURVEY 5: per-clip stage timings)")
+    parser.add_argument("--feature-cache", type=int, default=FEATURE_CACHE_CLIPS, metavar="N",
+                        help="pooled video features of the last N distinct clips stay on the device and are reused by later questions about the same "
+                             "video (ActivityNet-QA asks several per clip; the reference recomputes them, chat.py:137-144); 0 disables")
     return parser
 
 
@@ -35,60 +41,129 @@ def setup(args, components=None):
         from .model_utils import initialize_model
         if torch.cuda.is_available():
             torch.cuda.set_device(local)
+        if world > 1:
+            parallel.pin_rank_to_numa_node(local)
         components = initialize_model(args.model_name, args.projection_path)
     if getattr(args, "use_asr", False):
         raise NotImplementedError("--use_asr needs the WhisperX transcript stack, which is outside this package's hot path")
     return rank, world, components
 
 
+FEATURE_CACHE_CLIPS = 64      # x 0.73 MB ([356, 1024] fp16) at 224 px, 1.4 MB at 336 px
+
+
+class FeatureCache:
+    """LRU of pooled video features keyed by video path.  The prefetch thread only READS (`get`, which also refreshes recency and hands out a
+    reference, so an entry evicted before its group runs stays alive for that group); the device thread inserts."""
+
+    def __init__(self, capacity: int):
+        import collections
+        import threading
+        self.capacity, self._d, self._lock = max(int(capacity), 0), collections.OrderedDict(), threading.Lock()
+        self.hits = self.misses = 0
+
+    def get(self, path):
+        with self._lock:
+            f = self._d.get(path)
+            if f is not None:
+                self._d.move_to_end(path)
+                self.hits += 1
+            else:
+                self.misses += 1
+            return f
+
+    def put(self, path, feat):
+        if self.capacity <= 0:
+            return
+        with self._lock:
+            self._d[path] = feat
+            self._d.move_to_end(path)
+            while len(self._d) > self.capacity:
+                self._d.popitem(last=False)
+
+
+class _Cached:
+    """Marker the prefetch thread returns for a clip whose pooled features are in the cache (no frames were read)."""
+
+    def __init__(self, feat):
+        self.feat = feat
+
+
 def answer_tasks(args, tasks, components, load_frames, rank, world):
     """tasks: [{"path": str | None, "name": str, "question": str}] -> [str | None] in task order, identical on every rank."""
+    import json
+    import time
     from .. import parallel
-    from ..inference import build_prompt, video_chatgpt_infer, video_features, video_features_batch
+    from ..inference import build_prompt, video_chatgpt_infer_ids, video_features, video_features_batch
 
     model, vision_tower, tokenizer, image_processor, video_token_len = components
     use_se = model.get_model().vision_config.use_vid_start_end
     stop_strs = {}
+    cache = FeatureCache(getattr(args, "feature_cache", FEATURE_CACHE_CLIPS))
+    timings_path = getattr(args, "timings", None)
+    if timings_path and world > 1:
+        timings_path = f"{timings_path}.rank{rank}"
+    tfile = open(timings_path, "a") if timings_path else None
+    group_no = [0]
 
     from ..feature_extraction import PinnedRing
     ring = PinnedRing()
 
     def prepare(indices):
         """HOST half of a group, run one group ahead on the prefetch thread (parallel.run_sharded): decode / sample the frames of the group's
-        distinct clips into pinned memory.  -> {path: frames | Exception}"""
+        distinct clips into pinned memory -- except clips whose pooled features are still cached from an earlier group.
+        -> {path: frames | _Cached | Exception} (+ "__load_s__": {path: seconds})"""
         from ..feature_extraction import pin_frames
         ring.new_group()
-        clips = {}
+        clips, load_s = {}, {}
         for idx in indices:
             path = tasks[idx]["path"]
             if path is None or path in clips:
                 continue
+            hit = cache.get(path)
+            if hit is not None:
+                clips[path] = _Cached(hit)
+                continue
+            t0 = time.perf_counter()
             try:
                 clips[path] = pin_frames(load_frames(path), ring)
             except Exception as e:                                     # noqa: BLE001 -- reported per task below, like the reference's except
                 clips[path] = e
+            load_s[path] = time.perf_counter() - t0
+        clips["__load_s__"] = load_s
         return clips
+
+    def features_for(clips, tm):
+        """{path: pooled features} for every usable clip of a group: cached ones as they are, the others through ONE tower pass."""
+        feat_of = {p: f.feat for p, f in clips.items() if isinstance(f, _Cached)}
+        good = [p for p, f in clips.items() if not isinstance(f, (Exception, _Cached))]
+        if good:
+            try:
+                fresh = dict(zip(good, video_features_batch([clips[p] for p in good], vision_tower, image_processor, timings=tm)))
+            except Exception as e:                                     # noqa: BLE001 -- one bad clip must not take the group down
+                print(f"batched feature extraction failed ({e}); retrying the {len(good)} clips one by one")
+                fresh = {}
+                for p in good:
+                    try:
+                        fresh[p] = video_features(clips[p], vision_tower, image_processor)
+                    except Exception as e1:                            # noqa: BLE001
+                        clips[p] = e1
+            for p, f in fresh.items():
+                cache.put(p, f)
+            feat_of.update(fresh)
+        return feat_of
 
     def infer_batch(indices, clips=None):
         """-> (tokens [n, <= max_new] int32, lengths).  Length encoding: 0 = the task failed (no prediction), k + 1 = an answer of k tokens
         (k = 0 is a legitimate empty answer: the reference writes pred = '' when the first token is EOS).
-        DEVICE half of a group: ONE tower pass over the frames of all distinct clips of the group (inference.video_features_batch; bitwise
-        equal to per-clip passes), then batched prefill + decode."""
+        DEVICE half of a group: ONE tower pass over the frames of all distinct uncached clips of the group (inference.video_features_batch;
+        bitwise equal to per-clip passes), then batched prefill + decode with the per-chunk stop-string check."""
         if clips is None:
             clips = prepare(indices)
-        good = [p for p, f in clips.items() if not isinstance(f, Exception)]
-        feat_of = {}
-        if good:
-            try:
-                feat_of = dict(zip(good, video_features_batch([clips[p] for p in good], vision_tower, image_processor)))
-            except Exception as e:                                     # noqa: BLE001 -- one bad clip must not take the group down
-                print(f"batched feature extraction failed ({e}); retrying the {len(good)} clips one by one")
-                for p in good:
-                    try:
-                        feat_of[p] = video_features(clips[p], vision_tower, image_processor)
-                    except Exception as e1:                            # noqa: BLE001
-                        clips[p] = e1
-        prompts, feats, keep = [], [], []
+        load_s = clips.pop("__load_s__", {})
+        tm_v, tm_g = ({}, {}) if tfile else (None, None)
+        feat_of = features_for(clips, tm_v)
+        prompts, feats, keep, stops = [], [], [], []
         for j, idx in enumerate(indices):
             t = tasks[idx]
             if t["path"] is None:
@@ -102,6 +177,7 @@ def answer_tasks(args, tasks, components, load_frames, rank, world):
                 feats.append(feat_of[t["path"]])
                 stop_strs[idx] = stop
                 prompts.append(ids)
+                stops.append(stop)
                 keep.append(j)
             except Exception as e:                                     # noqa: BLE001 -- the reference's print-and-continue
                 print(f"Error processing video file '{t['name']}': {e}")
@@ -118,9 +194,11 @@ def answer_tasks(args, tasks, components, load_frames, rank, world):
             lens[j] = len(new) + 1
 
         if keep:
+            # a stop string that IS the EOS piece (pg-video-llava: "</s>") is already handled on the device by the EOS flag; the host check
+            # is for conv modes whose stop is ordinary text (video-chatgpt_v1: "###") -- without it every group decodes max_new_tokens steps
             try:
                 out = model.generate(prompts, video_spatio_temporal_features=torch.stack(feats), do_sample=False,
-                                     max_new_tokens=args.max_new_tokens).cpu()
+                                     max_new_tokens=args.max_new_tokens, stop_strings=stops, tokenizer=tokenizer, timings=tm_g).cpu()
                 for r, j in enumerate(keep):
                     record(j, out[r], len(prompts[r]))
             except Exception as e:                                     # noqa: BLE001
@@ -129,32 +207,60 @@ def answer_tasks(args, tasks, components, load_frames, rank, world):
                 for r, j in enumerate(keep):
                     try:
                         out = model.generate([prompts[r]], video_spatio_temporal_features=feats[r][None], do_sample=False,
-                                             max_new_tokens=args.max_new_tokens).cpu()
+                                             max_new_tokens=args.max_new_tokens, stop_strings=[stops[r]], tokenizer=tokenizer).cpu()
                         record(j, out[0], len(prompts[r]))
                     except Exception as e1:                            # noqa: BLE001
                         print(f"Error processing video file '{tasks[indices[j]]['name']}': {e1}")
+        if tfile:
+            n_fresh = sum(1 for f in clips.values() if not isinstance(f, (Exception, _Cached)))
+            for j, idx in enumerate(indices):
+                t = tasks[idx]
+                hit = isinstance(clips.get(t["path"]), _Cached)
+                tfile.write(json.dumps({"task": idx, "video": t["name"], "rank": rank, "group": group_no[0], "group_size": len(indices), "ok": lens[j] > 0,
+                                        "tokens": max(lens[j] - 1, 0), "feature_cache_hit": hit, "load_s": load_s.get(t["path"], 0.0),
+                                        "upload_ingest_s_group": (tm_v or {}).get("upload_ingest_s", 0.0), "tower_pool_s_group": (tm_v or {}).get("tower_pool_s", 0.0),
+                                        "clips_in_tower_pass": n_fresh, "prefill_s_group": (tm_g or {}).get("prefill_s"), "decode_s_group": (tm_g or {}).get("decode_s"),
+                                        "decode_steps_group": (tm_g or {}).get("steps")}) + "\n")
+            tfile.flush()
+        group_no[0] += 1
         return toks, lens
 
-    if args.do_sample:
-        preds = [None] * len(tasks)
-        for idx in parallel.shard_indices(len(tasks), rank, world):
+    def infer_sampled(indices, clips=None):
+        """--do_sample: the reference's temperature-0.2 sampling with its stopping criterion, one task at a time (video_chatgpt_infer's
+        path up to the detokenisation); the ids travel through the same fixed-shape collation as the greedy answers."""
+        if clips is None:
+            clips = prepare(indices)
+        clips.pop("__load_s__", None)
+        feat_of = features_for(clips, None)
+        toks = torch.zeros(len(indices), args.max_new_tokens, dtype=torch.int32)
+        lens = [0] * len(indices)
+        for j, idx in enumerate(indices):
             t = tasks[idx]
             try:
                 if t["path"] is None:
                     raise FileNotFoundError(t["name"])
-                preds[idx] = video_chatgpt_infer(load_frames(t["path"]), t["question"], args.conv_mode, model, vision_tower, tokenizer,
-                                                 image_processor, video_token_len, None, max_new_tokens=args.max_new_tokens)
+                if t["path"] not in feat_of:
+                    raise clips[t["path"]]
+                new, stop = video_chatgpt_infer_ids(None, t["question"], args.conv_mode, model, vision_tower, tokenizer, image_processor, video_token_len,
+                                                    None, max_new_tokens=args.max_new_tokens, features=feat_of[t["path"]])
+                new = new[:args.max_new_tokens]
+                stop_strs[idx] = stop
+                toks[j, :len(new)] = torch.tensor(new, dtype=torch.int32)
+                lens[j] = len(new) + 1
             except Exception as e:                                     # noqa: BLE001
                 print(f"Error processing video file '{t['name']}': {e}")
-        if world > 1:
-            gathered = [None] * world
-            torch.distributed.all_gather_object(gathered, preds)
-            preds = [next((g[i] for g in gathered if g[i] is not None), None) for i in range(len(tasks))]
-        return preds
+        return toks, lens
 
     device = vision_tower.device if hasattr(vision_tower, "device") else torch.device("cpu")
-    answers = parallel.run_sharded(len(tasks), infer_batch, args.max_new_tokens, rank, world, device, per_gpu_batch=args.batch,
-                                   length_offset=1, prepare=prepare)
+    try:
+        if args.do_sample:
+            answers = parallel.run_sharded(len(tasks), infer_sampled, args.max_new_tokens, rank, world, device, per_gpu_batch=1, length_offset=1, prepare=prepare)
+        else:
+            answers = parallel.run_sharded(len(tasks), infer_batch, args.max_new_tokens, rank, world, device, per_gpu_batch=args.batch,
+                                           length_offset=1, prepare=prepare)
+    finally:
+        if tfile:
+            tfile.close()
     from ..model.utils import first_stop_length
     preds = []
     for idx, ids in enumerate(answers):
@@ -162,8 +268,14 @@ def answer_tasks(args, tasks, components, load_frames, rank, world):
             preds.append(None)                                         # failed / missing: left out of the output like the reference's except
             continue
         stop = stop_strs.get(idx) or build_prompt("", args.conv_mode, 1, use_se)[1]
-        # The batched greedy loop runs to EOS / max_new_tokens; the reference's per-sample loop additionally stops when the conv mode's stop
-        # string shows up in the decoded tail (KeywordsStoppingCriteria).  Cut where that loop would have stopped, then clean like it does.
+        if args.do_sample:
+            # the ids already end where the reference's criterion stopped them; its own post-processing (inference.py:119-123)
+            text = tokenizer.batch_decode([ids], skip_special_tokens=True)[0]
+            preds.append(text.strip().rstrip(stop).strip())
+            continue
+        # The batched greedy loop stops a sequence at most one chunk late and cuts it where the reference's per-sample loop would have stopped
+        # (KeywordsStoppingCriteria); ids gathered from OTHER ranks went through the same cut.  Re-applying the cut here is idempotent and
+        # keeps this function correct for a generate() without stop support; then clean like the reference does.
         n = first_stop_length(ids, tokenizer, [stop]) if stop else None
         if n is not None:
             ids = ids[:n]

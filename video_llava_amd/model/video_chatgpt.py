@@ -369,7 +369,8 @@ class VideoChatGPTLlamaForCausalLM(nn.Module):
     @torch.no_grad()
     def generate(self, input_ids, video_spatio_temporal_features: Optional[torch.Tensor] = None, do_sample: bool = False,
                  temperature: float = 1.0, max_new_tokens: int = 1024, stopping_criteria=None, eos_token_id="config",
-                 chunk: int = 32, generator: Optional[torch.Generator] = None, top_k: int = 50, **_unused):
+                 chunk: int = 32, generator: Optional[torch.Generator] = None, top_k: int = 50,
+                 stop_strings: Optional[Sequence[Optional[str]]] = None, tokenizer=None, timings: Optional[dict] = None, **_unused):
         """Returns LongTensor [B, S + n_new] on the device, prompt echoed (checked by inference.py:115-117).
 
         input_ids: LongTensor [B, S] (equal-length prompts, the reference's case) or a list of id lists (ragged batch).
@@ -381,7 +382,12 @@ class VideoChatGPTLlamaForCausalLM(nn.Module):
             `generator` (a device torch.Generator; one uniform per sequence and step, so a run is reproducible from the seed and
             independent of the chunk size).
         Stopping criteria (B == 1, as in the reference) are evaluated on the host after each chunk, token by token in generation
-        order, and the output is cut at the first hit: the same ids as a per-token loop, the surplus steps of the chunk are discarded."""
+        order, and the output is cut at the first hit: the same ids as a per-token loop, the surplus steps of the chunk are discarded.
+        `stop_strings` (one per sequence, None = no stop string; needs `tokenizer`): the BATCHED form of the reference's
+        KeywordsStoppingCriteria (model/utils.py:6-26, passed at inference.py:101-102 with batch size 1): after every chunk each live
+        sequence's new ids are checked with `first_stop_length` (the exact per-token criterion, scanned incrementally); a sequence that
+        fired is cut there and finished, and the loop ends when every sequence has finished -- at most one chunk past the last stop.
+        `timings` (a dict) receives prefill_s / decode_s / steps of this call (host clock; the chunk boundaries are D2H syncs anyway)."""
         if torch.is_tensor(input_ids):
             seqs = [row.tolist() for row in input_ids.cpu()]
         else:
@@ -400,6 +406,16 @@ class VideoChatGPTLlamaForCausalLM(nn.Module):
             raise ValueError(f"`temperature` (={temperature}) has to be a strictly positive float; use do_sample=False for greedy decoding")
         if criteria:
             chunk = min(chunk, 16)                         # at most 15 surplus steps past a stop string
+        stops = list(stop_strings) if stop_strings is not None else None
+        if stops is not None:
+            if len(stops) != B or tokenizer is None:
+                raise ValueError("stop_strings needs one entry per sequence and the tokenizer that decodes them")
+            if not any(stops):
+                stops = None
+        scanned = [2] * B                                  # stop strings: prefixes shorter than this are known not to fire
+        final = [False] * B                                # ... and sequences whose stop check is complete
+        import time as _time
+        _t0 = _time.perf_counter()
 
         kv, nxt, _ = self.prefill(seqs, video_spatio_temporal_features, max_seq)
         u = None
@@ -425,8 +441,27 @@ class VideoChatGPTLlamaForCausalLM(nn.Module):
                     return True
             return False
 
+        def check_stops() -> bool:
+            """Per-chunk stop-string check of the live sequences; True = every sequence has finished."""
+            from .utils import first_stop_length
+            for b in range(B):
+                if final[b] or not stops[b] or len(new[b]) < 2:
+                    continue
+                n = first_stop_length(new[b], tokenizer, [stops[b]], start=scanned[b])
+                if n is not None:
+                    del new[b][n:]                         # a stop string ahead of an EOS of the same chunk wins, as in the per-token loop
+                    done[b] = final[b] = True
+                elif done[b]:
+                    final[b] = True                        # finished by EOS, no stop string before it
+                else:
+                    scanned[b] = len(new[b]) + 1
+            return all(done)
+
+        n_gen = 0
+        _t1 = _t0
         if max_new_tokens >= 1:
             stop = absorb(nxt.cpu())
+            _t1 = _time.perf_counter()
             n_gen = 1
             while not stop and n_gen < max_new_tokens:
                 n = min(chunk, max_new_tokens - n_gen)
@@ -440,7 +475,12 @@ class VideoChatGPTLlamaForCausalLM(nn.Module):
                     n_gen += 1
                     if stop:
                         break
+                if stops is not None and not stop:
+                    stop = check_stops()
                 nxt = toks[:, n - 1].contiguous()
+        if timings is not None:
+            _t2 = _time.perf_counter()
+            timings.update(prefill_s=_t1 - _t0, decode_s=_t2 - _t1, steps=n_gen, batch=B)
         width = max(len(s) + len(n_) for s, n_ in zip(seqs, new))
         pad = eos_i if eos_i >= 0 else 0
         out = torch.full((B, width), pad, dtype=torch.long)
