@@ -1,0 +1,96 @@
+// Lab (round 4): the fp8 decode GEMVs (through libpgv's internal launcher) at 7B and 13B shapes vs a bare streaming-read kernel of the same
+// bytes, for B = 1 and 8 sequences: how much of the fp8 GEMV's time is the activation operand (B = 1 requests 1/8 of the x lines).
+// Not product code.  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 gemv8_chain.hip -L../../video_llava_amd -lpgv -o gemv8_chain.exe
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include "../../include/pgv.h"
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+#define PK(x) do { int e = (x); if (e) { printf("%s: %s\n", #x, pgv_last_error()); exit(1); } } while (0)
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+struct GemvNorm {
+    const float* ssq_in = nullptr; int nparts_in = 0; int hidden = 1; float eps = 0.f;
+    const float* gamma = nullptr; void* xg = nullptr; float* ssq_out = nullptr;
+    float* amax_val = nullptr; int* amax_idx = nullptr;
+};
+int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void* x, int ldx, void* out, int ldo, int N, int K, int B, hipStream_t s,
+                    const float* wscale, const GemvNorm* norm);
+
+__global__ __launch_bounds__(1024) void stream_kernel(const char* base, size_t bytes, float* out) {
+    const size_t per_wg = bytes / gridDim.x;
+    const char* p = base + (size_t)blockIdx.x * per_wg;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const size_t nblk = per_wg / 1024;
+    u32x4 acc = {0, 0, 0, 0};
+    size_t j = w;
+    for (; j + 16 * 3 < nblk; j += 16 * 4) {
+        u32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load((const u32x4*)(p + (j + 16 * u) * 1024 + lane * 16));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc ^= v[u];
+    }
+    for (; j < nblk; j += 16) acc ^= __builtin_nontemporal_load((const u32x4*)(p + j * 1024 + lane * 16));
+    if ((acc[0] ^ acc[1] ^ acc[2] ^ acc[3]) == 0x12345677u) out[0] = 1;
+}
+
+template <typename F>
+static double time_chain(const char* name, hipStream_t s, int n, double bytes, F launch) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipGraph_t g; hipGraphExec_t ge;
+    for (int m = 0; m < n; ++m) launch(m);
+    CK(hipStreamSynchronize(s));
+    CK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    for (int m = 0; m < n; ++m) launch(m);
+    CK(hipStreamEndCapture(s, &g)); CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    float bestg = 1e30f;
+    for (int rep = 0; rep < 6; ++rep) {
+        CK(hipEventRecord(e0, s)); CK(hipGraphLaunch(ge, s)); CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (rep && ms < bestg) bestg = ms;
+    }
+    printf("%-44s %7.2f us  (%6.1f MB: %.2f TB/s)\n", name, bestg * 1e3 / n, bytes / 1e6, bytes / (bestg * 1e-3 / n) / 1e12);
+    CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+    return bestg * 1e3 / n;
+}
+
+int main(int argc, char** argv) {
+    setvbuf(stdout, nullptr, _IONBF, 0);
+    pgv_ctx* ctx; PK(pgv_ctx_create(0, &ctx));
+    hipStream_t s; CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    const int NM = 16;
+    const size_t slot = (size_t)27648 * 5120;                  // largest fp8 matrix (13B gate/up)
+    char* W; CK(hipMalloc(&W, slot * NM)); CK(hipMemset(W, 0x11, slot * NM));
+    float* sc; CK(hipMalloc(&sc, 32768 * 4));
+    { float* h = (float*)malloc(32768 * 4); for (int i = 0; i < 32768; ++i) h[i] = 1.0f; CK(hipMemcpy(sc, h, 32768 * 4, hipMemcpyHostToDevice)); free(h); }
+    char* x; CK(hipMalloc(&x, 16 * 13824 * 2)); CK(hipMemset(x, 0x11, 16 * 13824 * 2));
+    char* out; CK(hipMalloc(&out, 16 * 32768 * 4)); CK(hipMemset(out, 0, 16 * 32768 * 4));
+    float* resid; CK(hipMalloc(&resid, 16 * 5120 * 4)); CK(hipMemset(resid, 0, 16 * 5120 * 4));
+    float* gamma; CK(hipMalloc(&gamma, 5120 * 4)); CK(hipMemset(gamma, 0, 5120 * 4));
+    char* xg; CK(hipMalloc(&xg, 16 * 5120 * 2)); CK(hipMemset(xg, 0x11, 16 * 5120 * 2));
+    float* ssq; CK(hipMalloc(&ssq, (5120 / 16) * 16 * 4)); CK(hipMemset(ssq, 0, (5120 / 16) * 16 * 4));
+    for (int big = 0; big < 2; ++big) {
+        const int H = big ? 5120 : 4096, I = big ? 13824 : 11008;
+        printf("---- %s shapes, fp8 weights, bf16 activations ----\n", big ? "13B" : "7B");
+        GemvNorm cons; cons.ssq_in = ssq; cons.nparts_in = H / 16; cons.hidden = H; cons.eps = 1e-5f;
+        GemvNorm prod; prod.gamma = gamma; prod.xg = xg; prod.ssq_out = ssq; prod.hidden = H;
+        struct { const char* name; int mode, N, K; const GemvNorm* nm; int ldo; } cases[] = {
+            {"qkv (consumer)", 0, 3 * H, H, &cons, 3 * H}, {"gate/up (consumer)", 2, 2 * I, H, &cons, I},
+            {"o_proj (producer)", 5, H, H, &prod, H}, {"down (producer)", 5, H, I, &prod, H}};
+        double layer[3] = {0, 0, 0};
+        for (auto& c : cases) {
+            const double bytes = (double)c.N * c.K;
+            int col = 0;
+            for (int B : {8, 4, 1}) {
+                char nm[96]; snprintf(nm, sizeof nm, "%s N=%d K=%d B=%d", c.name, c.N, c.K, B);
+                layer[col++] += time_chain(nm, s, NM, bytes, [&](int m) {
+                    PK(pgv_launch_gemv(ctx, PGV_BF16, c.mode, W + slot * m, c.mode == 5 ? x : xg, c.K, c.mode == 5 ? (void*)resid : (void*)out, c.ldo, c.N, c.K, B, s, sc, c.nm));
+                });
+            }
+            time_chain("   bare stream of the same bytes", s, NM, bytes, [&](int m) { hipLaunchKernelGGL(stream_kernel, dim3(256), dim3(1024), 0, s, W + slot * m, (size_t)bytes, (float*)out); });
+        }
+        const double lb = 4.0 * H * H + 3.0 * (double)I * H;
+        printf("layer (4 GEMVs, %.1f MB): B=8 %.1f us (%.2f TB/s)  B=4 %.1f us  B=1 %.1f us (%.2f TB/s)\n", lb / 1e6, layer[0], lb / layer[0] / 1e6, layer[1], layer[2], lb / layer[2] / 1e6);
+    }
+    return 0;
+}

@@ -250,8 +250,8 @@ def _tiny_components(seed_c=21, seed_l=22, max_pos=2048):
 
 
 class _StopTok(_Tok):
-    """The synthetic tokenizer with chosen ids decoding to the text of a stop string ("###" is ordinary text for video-chatgpt_v1: it is
-    NOT a single-id keyword, so only the decoded-tail branch of KeywordsStoppingCriteria can see it)."""
+    """The synthetic tokenizer with chosen ids decoding to the text of a stop string ("###", the separator of conv mode `default`, is
+    NOT a single-id keyword here, so only the decoded-tail branch of KeywordsStoppingCriteria can see it)."""
 
     def __init__(self, vocab, stop_ids):
         super().__init__(vocab)
@@ -262,7 +262,7 @@ class _StopTok(_Tok):
 
 
 def test_batched_runner_stops_on_a_text_stop_string(ctx, tmp_path):
-    """conv mode video-chatgpt_v1 (stop string "###", not EOS) with the default-sized token budget: the batched greedy path must stop a group
+    """conv mode `default` (conv_v1_2: stop string "###", ordinary text, not EOS) with the default-sized token budget: the batched greedy path must stop a group
     within ONE chunk of the last sequence's stop string instead of decoding max_new_tokens steps, and every prediction must equal the
     per-sample path (video_chatgpt_infer with the reference's KeywordsStoppingCriteria, reference inference.py:101-102, model/utils.py:6-26)."""
     from video_llava_amd.eval import run_inference_qa_activitynet as qa
@@ -279,14 +279,18 @@ def test_batched_runner_stops_on_a_text_stop_string(ctx, tmp_path):
     plain = _Tok(lcfg.vocab)
     runs = {}
     for n, q in zip(names, qs):
-        prompt, _ = build_prompt(q["question"], "video-chatgpt_v1", V, True)
+        prompt, _ = build_prompt(q["question"], "default", V, True)
         ids = plain([prompt]).input_ids[0]
         pooled = ovis.spatio_temporal_pool_torch(ovis.clip_select_features(ovis.clip_preprocess(frames[n]), cw, ccfg))
         out = model.generate([ids], video_spatio_temporal_features=pooled.half().to(DEV)[None], do_sample=False, max_new_tokens=64)
         runs[n] = out[0, len(ids):].tolist()
-    stop_ids = {runs["s1"][5], runs["s2"][9], runs["s3"][40]}
+    def fresh_token(seq, upto):        # the latest position <= upto whose token has not occurred before it: the stop can fire no earlier there
+        return next(seq[i] for i in range(upto, 0, -1) if seq[i] not in seq[:i])
+    stop_ids = {fresh_token(runs["s1"], 5), fresh_token(runs["s2"], 9), fresh_token(runs["s3"], 40)}
     tok = _StopTok(lcfg.vocab, stop_ids)
-    last_stop = max(next(i for i, t in enumerate(runs[n]) if t in stop_ids) for n in names) + 1        # tokens until the LAST sequence has stopped
+    # tokens each per-token loop keeps: the criterion's first call only records the start, so the earliest stop is at n = 2
+    keep_n = {n: next(i for i, t in enumerate(runs[n]) if i >= 1 and t in stop_ids) + 1 for n in names}
+    last_stop = max(keep_n.values())                                                                   # tokens until the LAST sequence has stopped
     assert last_stop <= 41
     steps = {"n": 0}
     orig = type(model).decode_greedy
@@ -298,21 +302,21 @@ def test_batched_runner_stops_on_a_text_stop_string(ctx, tmp_path):
     try:
         args = qa.parse_args(["--video_dir", str(vd), "--gt_file_question", str(tmp_path / "q.json"), "--gt_file_answers", str(tmp_path / "a.json"),
                               "--output_dir", str(tmp_path / "out"), "--output_name", "p", "--model-name", "x", "--projection_path", "y",
-                              "--conv-mode", "video-chatgpt_v1", "--batch", "3", "--max_new_tokens", "1024", "--timings", str(tmp_path / "t.jsonl")])
+                              "--conv-mode", "default", "--batch", "3", "--max_new_tokens", "1024", "--timings", str(tmp_path / "t.jsonl")])
         out = qa.run_inference(args, components=(model, tower, tok, ip, V))
     finally:
         type(model).decode_greedy = orig
     assert [o["id"] for o in out] == ["s1_q", "s2_q", "s3_q"]
     assert steps["n"] + 1 <= last_stop + 32, f"{steps['n']} decode steps for a group whose last stop string ends at token {last_stop}"
     for o, n in zip(out, names):
-        ref = video_chatgpt_infer(frames[n], o["question"], "video-chatgpt_v1", model, tower, tok, ip, V, do_sample=False, max_new_tokens=1024)
+        ref = video_chatgpt_infer(frames[n], o["question"], "default", model, tower, tok, ip, V, do_sample=False, max_new_tokens=1024)
         assert o["pred"] == ref and "###" not in o["pred"], (n, o["pred"], ref)
         assert len(o["pred"].split()) < 45
     # --timings: one JSON line per task with the stage times of its group
     lines = [json.loads(x) for x in open(tmp_path / "t.jsonl")]
     assert [x["task"] for x in lines] == [0, 1, 2] and all(x["ok"] and x["group_size"] == 3 and not x["feature_cache_hit"] for x in lines)
     assert all(x["tower_pool_s_group"] > 0 and x["prefill_s_group"] > 0 and x["decode_s_group"] > 0 and x["load_s"] > 0 for x in lines)
-    assert lines[0]["tokens"] == 6 + 1 - 1 or lines[0]["tokens"] >= 2
+    assert [x["tokens"] for x in lines] == [keep_n[n] for n in names]
 
 
 def test_runner_feature_cache_and_sampling_collation(ctx, tmp_path):

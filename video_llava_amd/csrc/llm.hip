@@ -23,7 +23,8 @@ int pgv_launch_unpack_blocked(int dtype, const void* src, float* dst, long long 
                               long long rows, hipStream_t s);
 int pgv_launch_final_prep(int dtype, const float* resid, const float* gamma, void* xg, float* ssq, int B, int H, hipStream_t s);
 int pgv_launch_decode_attn(pgv_ctx* ctx, int dtype, const void* qkv, const int* pos, const void* rope, void* Kc, void* Vc, void* out, int B, int H,
-                           int heads, int max_seq, double bytes, hipStream_t s);
+                           int heads, int max_seq, double bytes, hipStream_t s, float* part, unsigned* ticket);
+constexpr int kDattnSplitMax = 8, kDattnPart = 128 + 2;       // llm_kernels.hip: DSPLIT_MAX, DPART
 int pgv_launch_sample(const float* logits, int V, int B, float temperature, int top_k, const float* u, int u_stride, int u_by_step, int* next, int* pos,
                       int* step, int* hist, int hist_stride, int* done, int eos, int advance, hipStream_t s);
 int pgv_launch_argmax_parts(const float* val, const int* idx, int nblk, int V, int B, int* next, int* pos, int* step, int* hist, int hist_stride, int* done,
@@ -70,6 +71,7 @@ struct pgv_kv {
     float* resid; void* xn; void* qkv; void* ao; void* act; float* logits;
     float* amax_val; int* amax_idx;     // greedy candidates of the lm_head GEMV: [vocab_cap / 16][16]
     float* ssq;                         // sum-of-squares partials of the folded RMSNorm: [hidden / 16][16] (see GemvArgs in llm_kernels.hip)
+    float* dattn_part; unsigned* dattn_ticket;   // context-split decode attention: partial states [B * heads][8][130], arrival tickets [B * heads] (zero between launches)
     int *d_pos, *d_cur, *d_step, *d_done, *d_hist;
     std::vector<int> h_len;
     std::vector<int> h_meta;           // staging for prefill row maps (kept alive across the async copy)
@@ -298,7 +300,7 @@ extern "C" int pgv_kv_create(pgv_ctx* ctx, pgv_llm* llm, int batch, int max_seq,
     const size_t o_cache = take(per * 2 * L);
     const size_t o_resid = take(B * H * 4), o_xn = take(B * H * 2), o_qkv = take(B * 3 * H * 2), o_ao = take(B * H * 2), o_act = take(B * I * 2),
                  o_logits = take(B * V * 4), o_ssq = take((H / 16) * 16 * 4), o_av = take((V / 16) * 16 * 4), o_ai = take((V / 16) * 16 * 4), o_ints = take((4 * B + B * (size_t)max_seq) * 4),
-                 o_u = take(B * (size_t)max_seq * 4);
+                 o_u = take(B * (size_t)max_seq * 4), o_dpart = take(B * llm->cfg.heads * (size_t)kDattnSplitMax * kDattnPart * 4), o_dtick = take(B * llm->cfg.heads * 4);
     hipError_t e = hipMalloc((void**)&kv->blob, off);
     if (e != hipSuccess) { delete kv; pgv_set_error("pgv_kv_create: hipMalloc(%zu MiB): %s", off >> 20, hipGetErrorString(e)); return PGV_ENOMEM; }
     char* b = kv->blob;
@@ -307,7 +309,9 @@ extern "C" int pgv_kv_create(pgv_ctx* ctx, pgv_llm* llm, int batch, int max_seq,
     int* ints = (int*)(b + o_ints);
     kv->d_pos = ints; kv->d_cur = ints + B; kv->d_step = ints + 2 * B; kv->d_done = ints + 3 * B; kv->d_hist = ints + 4 * B;
     kv->d_u = (float*)(b + o_u);
+    kv->dattn_part = (float*)(b + o_dpart); kv->dattn_ticket = (unsigned*)(b + o_dtick);
     e = hipMemset(ints, 0, (4 * B + B * (size_t)max_seq) * 4);
+    if (e == hipSuccess) e = hipMemset(kv->dattn_ticket, 0, B * llm->cfg.heads * 4);
     if (e == hipSuccess) e = hipMemset(kv->ssq, 0, (H / 16) * 16 * 4);
     if (e != hipSuccess) { (void)hipFree(kv->blob); delete kv; pgv_set_error("pgv_kv_create: memset: %s", hipGetErrorString(e)); return PGV_EHIP; }
     kv->h_len.assign(batch, 0);
@@ -460,7 +464,7 @@ static int decode_enqueue_unfolded(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int eos
         const bool q8 = m->fp8;
         PGV_TRY(pgv_launch_rmsnorm(m->dtype, kv->resid, l.in_g, m->cfg.eps, kv->xn, B, H, s));
         PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_STORE16, q8 ? l.q_wqkv : l.wqkv, kv->xn, H, kv->qkv, 3 * H, 3 * H, H, B, s, q8 ? l.s_wqkv : nullptr, nullptr));
-        PGV_TRY(pgv_launch_decode_attn(ctx, m->dtype, kv->qkv, kv->d_pos, m->rope, kv->Kc[li], kv->Vc[li], kv->ao, B, H, heads, kv->max_seq, kv_bytes, s));
+        PGV_TRY(pgv_launch_decode_attn(ctx, m->dtype, kv->qkv, kv->d_pos, m->rope, kv->Kc[li], kv->Vc[li], kv->ao, B, H, heads, kv->max_seq, kv_bytes, s, kv->dattn_part, kv->dattn_ticket));
         PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_RESID, q8 ? l.q_wo : l.wo, kv->ao, H, kv->resid, H, H, H, B, s, q8 ? l.s_wo : nullptr, nullptr));
         PGV_TRY(pgv_launch_rmsnorm(m->dtype, kv->resid, l.post_g, m->cfg.eps, kv->xn, B, H, s));
         PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_SWIGLU, q8 ? l.q_wgu : l.wgu, kv->xn, H, kv->act, I, 2 * I, H, B, s, q8 ? l.s_wgu : nullptr, nullptr));
@@ -488,7 +492,7 @@ static int decode_enqueue(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int eos, int fla
         const bool q8 = m->fp8;
         GemvNorm cons; cons.ssq_in = kv->ssq; cons.nparts_in = parts_in; cons.hidden = H; cons.eps = m->cfg.eps;
         PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_STORE16, q8 ? l.q_wqkv : l.wqkv, kv->xn, H, kv->qkv, 3 * H, 3 * H, H, B, s, q8 ? l.s_wqkv : nullptr, &cons));
-        PGV_TRY(pgv_launch_decode_attn(ctx, m->dtype, kv->qkv, kv->d_pos, m->rope, kv->Kc[li], kv->Vc[li], kv->ao, B, H, heads, kv->max_seq, kv_bytes, s));
+        PGV_TRY(pgv_launch_decode_attn(ctx, m->dtype, kv->qkv, kv->d_pos, m->rope, kv->Kc[li], kv->Vc[li], kv->ao, B, H, heads, kv->max_seq, kv_bytes, s, kv->dattn_part, kv->dattn_ticket));
         GemvNorm prod; prod.gamma = l.post_g; prod.xg = kv->xn; prod.ssq_out = kv->ssq;
         PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_RESIDNORM, q8 ? l.q_wo : l.wo, kv->ao, H, kv->resid, H, H, H, B, s, q8 ? l.s_wo : nullptr, &prod));
         cons.nparts_in = nparts;

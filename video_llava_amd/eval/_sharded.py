@@ -136,7 +136,16 @@ def answer_tasks(args, tasks, components, load_frames, rank, world):
     def features_for(clips, tm):
         """{path: pooled features} for every usable clip of a group: cached ones as they are, the others through ONE tower pass."""
         feat_of = {p: f.feat for p, f in clips.items() if isinstance(f, _Cached)}
-        good = [p for p, f in clips.items() if not isinstance(f, (Exception, _Cached))]
+        good = []
+        for p, f in clips.items():
+            if isinstance(f, (Exception, _Cached)):
+                continue
+            hit = cache.get(p)               # the prefetch thread runs one group ahead: a clip it loaded may have been pooled by the group in between
+            if hit is not None:
+                feat_of[p] = hit
+                clips[p] = _Cached(hit)
+            else:
+                good.append(p)
         if good:
             try:
                 fresh = dict(zip(good, video_features_batch([clips[p] for p in good], vision_tower, image_processor, timings=tm)))
