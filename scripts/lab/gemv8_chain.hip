@@ -12,6 +12,7 @@ struct GemvNorm {
     const float* ssq_in = nullptr; int nparts_in = 0; int hidden = 1; float eps = 0.f;
     const float* gamma = nullptr; void* xg = nullptr; float* ssq_out = nullptr;
     float* amax_val = nullptr; int* amax_idx = nullptr;
+    float* kpart = nullptr; unsigned* kticket = nullptr;
 };
 int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void* x, int ldx, void* out, int ldo, int N, int K, int B, hipStream_t s,
                     const float* wscale, const GemvNorm* norm);
@@ -69,11 +70,12 @@ int main(int argc, char** argv) {
     float* gamma; CK(hipMalloc(&gamma, 5120 * 4)); CK(hipMemset(gamma, 0, 5120 * 4));
     char* xg; CK(hipMalloc(&xg, 16 * 5120 * 2)); CK(hipMemset(xg, 0x11, 16 * 5120 * 2));
     float* ssq; CK(hipMalloc(&ssq, (5120 / 16) * 16 * 4)); CK(hipMemset(ssq, 0, (5120 / 16) * 16 * 4));
+    float* kpart; CK(hipMalloc(&kpart, (5120 / 16) * 4 * 1024)); unsigned* ktick; CK(hipMalloc(&ktick, (5120 / 16) * 4)); CK(hipMemset(ktick, 0, (5120 / 16) * 4));
     for (int big = 0; big < 2; ++big) {
         const int H = big ? 5120 : 4096, I = big ? 13824 : 11008;
         printf("---- %s shapes, fp8 weights, bf16 activations ----\n", big ? "13B" : "7B");
         GemvNorm cons; cons.ssq_in = ssq; cons.nparts_in = H / 16; cons.hidden = H; cons.eps = 1e-5f;
-        GemvNorm prod; prod.gamma = gamma; prod.xg = xg; prod.ssq_out = ssq; prod.hidden = H;
+        GemvNorm prod; prod.gamma = gamma; prod.xg = xg; prod.ssq_out = ssq; prod.hidden = H; prod.kpart = kpart; prod.kticket = ktick;
         struct { const char* name; int mode, N, K; const GemvNorm* nm; int ldo; } cases[] = {
             {"qkv (consumer)", 0, 3 * H, H, &cons, 3 * H}, {"gate/up (consumer)", 2, 2 * I, H, &cons, I},
             {"o_proj (producer)", 5, H, H, &prod, H}, {"down (producer)", 5, H, I, &prod, H}};
@@ -81,7 +83,7 @@ int main(int argc, char** argv) {
         for (auto& c : cases) {
             const double bytes = (double)c.N * c.K;
             int col = 0;
-            for (int B : {8, 4, 1}) {
+            for (int B : {8, 1}) {
                 char nm[96]; snprintf(nm, sizeof nm, "%s N=%d K=%d B=%d", c.name, c.N, c.K, B);
                 layer[col++] += time_chain(nm, s, NM, bytes, [&](int m) {
                     PK(pgv_launch_gemv(ctx, PGV_BF16, c.mode, W + slot * m, c.mode == 5 ? x : xg, c.K, c.mode == 5 ? (void*)resid : (void*)out, c.ldo, c.N, c.K, B, s, sc, c.nm));
@@ -90,7 +92,7 @@ int main(int argc, char** argv) {
             time_chain("   bare stream of the same bytes", s, NM, bytes, [&](int m) { hipLaunchKernelGGL(stream_kernel, dim3(256), dim3(1024), 0, s, W + slot * m, (size_t)bytes, (float*)out); });
         }
         const double lb = 4.0 * H * H + 3.0 * (double)I * H;
-        printf("layer (4 GEMVs, %.1f MB): B=8 %.1f us (%.2f TB/s)  B=4 %.1f us  B=1 %.1f us (%.2f TB/s)\n", lb / 1e6, layer[0], lb / layer[0] / 1e6, layer[1], layer[2], lb / layer[2] / 1e6);
+        printf("layer (4 GEMVs, %.1f MB): B=8 %.1f us (%.2f TB/s)  B=1 %.1f us (%.2f TB/s)\n", lb / 1e6, layer[0], lb / layer[0] / 1e6, layer[1], lb / layer[1] / 1e6);
     }
     return 0;
 }
