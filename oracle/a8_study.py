@@ -6,7 +6,7 @@ fp8 x fp8 MFMA (v_mfma_f32_16x16x32_fp8_fp8) needs the activation operand in e4m
 depth, what that does to the logits: the fp32 oracle of oracle/llm.py on the fp8-dequantised weights of the 13B full-depth case
 (oracle/fulldepth.py), once as is and once with the INPUT of every linear layer (q/k/v, o, gate/up, down, lm_head) rounded to e4m3 with a
 per-token power-of-two scale chosen from the exact amax (the most favourable activation quantiser a decode GEMV could implement).
-Usage: python oracle/a8_study.py [7b|13b] [n_new]"""
+Usage: python oracle/a8_study.py [7b|13b] [n_new] [e4m3|hilo]"""
 from __future__ import annotations
 
 import os
@@ -21,9 +21,18 @@ from oracle import fulldepth as fd      # noqa: E402
 from oracle import llm as ollm          # noqa: E402
 
 
+MODE = "e4m3"      # "e4m3": one e4m3 value per activation;  "hilo": activation = hi + lo, both e4m3 (two fp8 MFMAs per fragment)
+
+
 def q_e4m3_rows(x: torch.Tensor) -> torch.Tensor:
-    """Per-row (token) power-of-two scale from the exact amax, e4m3 round-to-nearest-even, dequantised."""
-    return ollm.quantize_e4m3_rows(x)
+    """Per-row (token) power-of-two scale from the exact amax, e4m3 round-to-nearest-even, dequantised.  MODE "hilo" (VERDICT r3 #3c, the
+    one point between "bf16 activations" and "plain e4m3"): x ~ hi + lo with hi = e4m3(x) and lo = e4m3(x - hi), each under its own
+    exact-amax power-of-two row scale -- what two v_mfma_f32_16x16x32_fp8_fp8 per weight fragment (W x hi, W x lo, both accumulating
+    in fp32) would compute, with no in-register widening of the weights."""
+    hi = ollm.quantize_e4m3_rows(x)
+    if MODE != "hilo":
+        return hi
+    return hi + ollm.quantize_e4m3_rows(x - hi)
 
 
 class A8Oracle(ollm.LlamaOracle):
@@ -70,8 +79,10 @@ class A8Oracle(ollm.LlamaOracle):
 
 
 def main():
+    global MODE
     name = sys.argv[1] if len(sys.argv) > 1 else "13b"
     n_tf = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+    MODE = sys.argv[3] if len(sys.argv) > 3 else "e4m3"
     c = fd.CASES[name]
     cfg = c["cfg"]
     t0 = time.time()
@@ -96,7 +107,7 @@ def main():
     agree = (a8.argmax(-1) == ref.argmax(-1))
     sigma = (a8 - ref).std(dim=-1)
     safe = margins > 6 * sigma
-    print(f"{name} fp8 weights, {cfg.layers} layers, {len(cont) + 1} teacher-forced positions: logits error with e4m3 activations "
+    print(f"{name} fp8 weights, {cfg.layers} layers, {len(cont) + 1} teacher-forced positions: logits error with {MODE} activations "
           f"{float(err[0]):.3e} at the prefill position, median {float(err.median()):.3e}, worst {float(err.max()):.3e}; argmax agreement "
           f"{int(agree.sum())}/{len(agree)}; positions whose fp32 margin exceeds 6 sigma of that noise: {int(safe.sum())} "
           f"(all agree: {bool(agree[safe].all())}); weight-only fp8 on the GPU at the same depth: 7.0e-3 (fp16 activations), 6.7e-2 (bf16)")

@@ -12,7 +12,6 @@ struct GemvNorm {
     const float* ssq_in = nullptr; int nparts_in = 0; int hidden = 1; float eps = 0.f;
     const float* gamma = nullptr; void* xg = nullptr; float* ssq_out = nullptr;
     float* amax_val = nullptr; int* amax_idx = nullptr;
-    float* kpart = nullptr; unsigned* kticket = nullptr;
 };
 int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void* x, int ldx, void* out, int ldo, int N, int K, int B, hipStream_t s,
                     const float* wscale, const GemvNorm* norm);
@@ -64,18 +63,19 @@ int main(int argc, char** argv) {
     char* W; CK(hipMalloc(&W, slot * NM)); CK(hipMemset(W, 0x11, slot * NM));
     float* sc; CK(hipMalloc(&sc, 32768 * 4));
     { float* h = (float*)malloc(32768 * 4); for (int i = 0; i < 32768; ++i) h[i] = 1.0f; CK(hipMemcpy(sc, h, 32768 * 4, hipMemcpyHostToDevice)); free(h); }
-    char* x; CK(hipMalloc(&x, 16 * 13824 * 2)); CK(hipMemset(x, 0x11, 16 * 13824 * 2));
+    char* x; CK(hipMalloc(&x, 16 * (13824 + 1024) * 2)); CK(hipMemset(x, 0x11, 16 * (13824 + 1024) * 2));
+    const int xpad = getenv("XPAD") ? atoi(getenv("XPAD")) : 0;      // extra elements per activation row (channel-conflict experiment)
+    printf("activation row stride = K + %d elements\n", xpad);
     char* out; CK(hipMalloc(&out, 16 * 32768 * 4)); CK(hipMemset(out, 0, 16 * 32768 * 4));
     float* resid; CK(hipMalloc(&resid, 16 * 5120 * 4)); CK(hipMemset(resid, 0, 16 * 5120 * 4));
     float* gamma; CK(hipMalloc(&gamma, 5120 * 4)); CK(hipMemset(gamma, 0, 5120 * 4));
-    char* xg; CK(hipMalloc(&xg, 16 * 5120 * 2)); CK(hipMemset(xg, 0x11, 16 * 5120 * 2));
+    char* xg; CK(hipMalloc(&xg, 16 * (5120 + 1024) * 2)); CK(hipMemset(xg, 0x11, 16 * (5120 + 1024) * 2));
     float* ssq; CK(hipMalloc(&ssq, (5120 / 16) * 16 * 4)); CK(hipMemset(ssq, 0, (5120 / 16) * 16 * 4));
-    float* kpart; CK(hipMalloc(&kpart, (5120 / 16) * 4 * 1024)); unsigned* ktick; CK(hipMalloc(&ktick, (5120 / 16) * 4)); CK(hipMemset(ktick, 0, (5120 / 16) * 4));
     for (int big = 0; big < 2; ++big) {
         const int H = big ? 5120 : 4096, I = big ? 13824 : 11008;
         printf("---- %s shapes, fp8 weights, bf16 activations ----\n", big ? "13B" : "7B");
         GemvNorm cons; cons.ssq_in = ssq; cons.nparts_in = H / 16; cons.hidden = H; cons.eps = 1e-5f;
-        GemvNorm prod; prod.gamma = gamma; prod.xg = xg; prod.ssq_out = ssq; prod.hidden = H; prod.kpart = kpart; prod.kticket = ktick;
+        GemvNorm prod; prod.gamma = gamma; prod.xg = xg; prod.ssq_out = ssq; prod.hidden = H;
         struct { const char* name; int mode, N, K; const GemvNorm* nm; int ldo; } cases[] = {
             {"qkv (consumer)", 0, 3 * H, H, &cons, 3 * H}, {"gate/up (consumer)", 2, 2 * I, H, &cons, I},
             {"o_proj (producer)", 5, H, H, &prod, H}, {"down (producer)", 5, H, I, &prod, H}};
@@ -86,7 +86,7 @@ int main(int argc, char** argv) {
             for (int B : {8, 1}) {
                 char nm[96]; snprintf(nm, sizeof nm, "%s N=%d K=%d B=%d", c.name, c.N, c.K, B);
                 layer[col++] += time_chain(nm, s, NM, bytes, [&](int m) {
-                    PK(pgv_launch_gemv(ctx, PGV_BF16, c.mode, W + slot * m, c.mode == 5 ? x : xg, c.K, c.mode == 5 ? (void*)resid : (void*)out, c.ldo, c.N, c.K, B, s, sc, c.nm));
+                    PK(pgv_launch_gemv(ctx, PGV_BF16, c.mode, W + slot * m, c.mode == 5 ? x : xg, c.K + xpad, c.mode == 5 ? (void*)resid : (void*)out, c.ldo, c.N, c.K, B, s, sc, c.nm));
                 });
             }
             time_chain("   bare stream of the same bytes", s, NM, bytes, [&](int m) { hipLaunchKernelGGL(stream_kernel, dim3(256), dim3(1024), 0, s, W + slot * m, (size_t)bytes, (float*)out); });

@@ -12,7 +12,6 @@ struct GemvNorm {
     const float* ssq_in = nullptr; int nparts_in = 0; int hidden = 1; float eps = 0.f;
     const float* gamma = nullptr; void* xg = nullptr; float* ssq_out = nullptr;
     float* amax_val = nullptr; int* amax_idx = nullptr;
-    float* kpart = nullptr; unsigned* kticket = nullptr;
 };
 int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void* x, int ldx, void* out, int ldo, int N, int K, int B, hipStream_t s,
                     const float* wscale, const GemvNorm* norm);

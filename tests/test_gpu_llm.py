@@ -471,18 +471,14 @@ def test_folded_rmsnorm_outlier_channels_and_wide_gammas(ctx, dtype, tol):
     assert worst < tol
 
 
-@pytest.mark.parametrize("switch", ["PGV_LLM_NORM_FOLD=0", "PGV_GEMV_PROD_TL=4", "PGV_GEMV_PROD_TL=2", "PGV_GEMV_PROD_TL=1", "PGV_DATTN_SPLIT=1", "PGV_DATTN_SPLIT=2",
-                                    "PGV_DATTN_SPLIT=8"])
+@pytest.mark.parametrize("switch", ["PGV_LLM_NORM_FOLD=0", "PGV_DATTN_SPLIT=1", "PGV_DATTN_SPLIT=4", "PGV_DATTN_SPLIT=8"])
 def test_decoder_path_switches_match_goldens(ctx, golden_dir, switch):
     """Every decode-path variant must reproduce the same reference-generated goldens as the default (the switches are read once per process,
     so each runs in a child process):
       PGV_LLM_NORM_FOLD=0   a standalone RMSNorm in front of every consumer GEMV (HF's order of operations): the bisect switch for
                             real-checkpoint regressions;
-      PGV_GEMV_PROD_TL=n    the residual producers (o_proj, down_proj) as n row blocks x n K ranges per workgroup group with the fence-free
-                            cross-workgroup sum (default 4 at 7B / 13B shapes; the tiny model's K is too short for the default, so the forced
-                            values are what puts the protocol under the goldens);
-      PGV_DATTN_SPLIT=n     decode attention cut into n context parts per (sequence, head) (default: 4 for head counts like the tiny model's
-                            and 13B's, 1 for 7B)."""
+      PGV_DATTN_SPLIT=n     decode attention cut into n context parts per (sequence, head), merged across workgroups without fences
+                            (default: 2 for head counts like the tiny model's and 13B's, 1 for 7B)."""
     import subprocess
     import sys
     code = f'''

@@ -71,7 +71,6 @@ struct pgv_kv {
     float* resid; void* xn; void* qkv; void* ao; void* act; float* logits;
     float* amax_val; int* amax_idx;     // greedy candidates of the lm_head GEMV: [vocab_cap / 16][16]
     float* ssq;                         // sum-of-squares partials of the folded RMSNorm: [hidden / 16][16] (see GemvArgs in llm_kernels.hip)
-    float* gemv_kpart; unsigned* gemv_kticket;   // K-split residual producers (llm_kernels.hip GemvArgs::kpart): [hidden / 16][4][256] floats, [hidden / 16] tickets
     float* dattn_part; unsigned* dattn_ticket;   // context-split decode attention: partial states [B * heads][8][130], arrival tickets [B * heads] (zero between launches)
     int *d_pos, *d_cur, *d_step, *d_done, *d_hist;
     std::vector<int> h_len;
@@ -301,8 +300,7 @@ extern "C" int pgv_kv_create(pgv_ctx* ctx, pgv_llm* llm, int batch, int max_seq,
     const size_t o_cache = take(per * 2 * L);
     const size_t o_resid = take(B * H * 4), o_xn = take(B * H * 2), o_qkv = take(B * 3 * H * 2), o_ao = take(B * H * 2), o_act = take(B * I * 2),
                  o_logits = take(B * V * 4), o_ssq = take((H / 16) * 16 * 4), o_av = take((V / 16) * 16 * 4), o_ai = take((V / 16) * 16 * 4), o_ints = take((4 * B + B * (size_t)max_seq) * 4),
-                 o_u = take(B * (size_t)max_seq * 4), o_dpart = take(B * llm->cfg.heads * (size_t)kDattnSplitMax * kDattnPart * 4), o_dtick = take(B * llm->cfg.heads * 4),
-                 o_kpart = take((H / 16) * 4 * 256 * 4), o_ktick = take((H / 16) * 4);
+                 o_u = take(B * (size_t)max_seq * 4), o_dpart = take(B * llm->cfg.heads * (size_t)kDattnSplitMax * kDattnPart * 4), o_dtick = take(B * llm->cfg.heads * 4);
     hipError_t e = hipMalloc((void**)&kv->blob, off);
     if (e != hipSuccess) { delete kv; pgv_set_error("pgv_kv_create: hipMalloc(%zu MiB): %s", off >> 20, hipGetErrorString(e)); return PGV_ENOMEM; }
     char* b = kv->blob;
@@ -314,8 +312,6 @@ extern "C" int pgv_kv_create(pgv_ctx* ctx, pgv_llm* llm, int batch, int max_seq,
     kv->dattn_part = (float*)(b + o_dpart); kv->dattn_ticket = (unsigned*)(b + o_dtick);
     e = hipMemset(ints, 0, (4 * B + B * (size_t)max_seq) * 4);
     if (e == hipSuccess) e = hipMemset(kv->dattn_ticket, 0, B * llm->cfg.heads * 4);
-    kv->gemv_kpart = (float*)(b + o_kpart); kv->gemv_kticket = (unsigned*)(b + o_ktick);
-    if (e == hipSuccess) e = hipMemset(kv->gemv_kticket, 0, (H / 16) * 4);
     if (e == hipSuccess) e = hipMemset(kv->ssq, 0, (H / 16) * 16 * 4);
     if (e != hipSuccess) { (void)hipFree(kv->blob); delete kv; pgv_set_error("pgv_kv_create: memset: %s", hipGetErrorString(e)); return PGV_EHIP; }
     kv->h_len.assign(batch, 0);
@@ -497,7 +493,7 @@ static int decode_enqueue(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int eos, int fla
         GemvNorm cons; cons.ssq_in = kv->ssq; cons.nparts_in = parts_in; cons.hidden = H; cons.eps = m->cfg.eps;
         PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_STORE16, q8 ? l.q_wqkv : l.wqkv, kv->xn, H, kv->qkv, 3 * H, 3 * H, H, B, s, q8 ? l.s_wqkv : nullptr, &cons));
         PGV_TRY(pgv_launch_decode_attn(ctx, m->dtype, kv->qkv, kv->d_pos, m->rope, kv->Kc[li], kv->Vc[li], kv->ao, B, H, heads, kv->max_seq, kv_bytes, s, kv->dattn_part, kv->dattn_ticket));
-        GemvNorm prod; prod.gamma = l.post_g; prod.xg = kv->xn; prod.ssq_out = kv->ssq; prod.kpart = kv->gemv_kpart; prod.kticket = kv->gemv_kticket;
+        GemvNorm prod; prod.gamma = l.post_g; prod.xg = kv->xn; prod.ssq_out = kv->ssq;
         PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_RESIDNORM, q8 ? l.q_wo : l.wo, kv->ao, H, kv->resid, H, H, H, B, s, q8 ? l.s_wo : nullptr, &prod));
         cons.nparts_in = nparts;
         PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_SWIGLU, q8 ? l.q_wgu : l.wgu, kv->xn, H, kv->act, I, 2 * I, H, B, s, q8 ? l.s_wgu : nullptr, &cons));

@@ -286,9 +286,6 @@ struct GemvArgs {
     // GV_F32 (lm_head): per-workgroup greedy candidates -- the largest logit of the workgroup's 16 rows and its (smallest) index per batch
     // column -- so the token pick scans N / 16 candidates instead of N logits (null: not wanted)
     float* amax_val; int* amax_idx;                            // [gridDim.x][16]
-    // GV_RESIDNORM with TL > 1 row blocks per workgroup: the K range is cut in `ksplit` parts, one workgroup each (see the kernel's epilogue)
-    int rot;                                                   // rotate every workgroup's K sweep (see the kernel); 0 = all start at k = 0
-    int ksplit; float* kpart; unsigned* kticket;               // kpart [groups][ksplit][TL][64][4] fp32, kticket [groups] (zero between launches)
 };
 
 // W8 = true streams the fp8 (e4m3) blocked copy of the matrix: one 16-byte load per lane carries the A fragments of TWO consecutive
@@ -339,20 +336,10 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
     const int kblocks = p.K >> 5;
     int rb[TILES];
     if constexpr (MODE == GV_SWIGLU) {
-        static_assert(TILES % 2 == 0, "SwiGLU: gate / up row-block pairs");
-#pragma unroll
-        for (int q = 0; q < TILES / 2; ++q) {                    // TILES / 2 output column blocks per workgroup, each a (gate, up) pair of row blocks
-            const int i0 = ((int)blockIdx.x * (TILES / 2) + q) * 16;
-            const int base = (i0 >> 5) * 64 + (i0 & 31);         // packed gate row (multiple of 16)
-            rb[2 * q] = base >> 4;                               // gate row block
-            rb[2 * q + 1] = (base + 32) >> 4;                    // matching up row block
-        }
-    } else if constexpr (MODE == GV_RESIDNORM) {
-        // 2-D decomposition of the residual producers (round 4): workgroup = TL row blocks x one of `ksplit` K ranges.  A 16-row workgroup
-        // reads as many activation lines as fp8 weight lines (x is B x K 16-bit values per workgroup whatever its row count); TL row blocks
-        // share them, and cutting K by the same factor keeps the workgroup count (one or more per CU) and its weight bytes unchanged.
-#pragma unroll
-        for (int t = 0; t < TILES; ++t) rb[t] = ((int)blockIdx.x / p.ksplit) * TILES + t;
+        const int i0 = blockIdx.x * 16;                          // output column block
+        const int base = (i0 >> 5) * 64 + (i0 & 31);             // packed gate row (multiple of 16)
+        rb[0] = base >> 4;                                       // gate row block
+        rb[1] = (base + 32) >> 4;                                // matching up row block
     } else {
 #pragma unroll
         for (int t = 0; t < TILES; ++t) rb[t] = blockIdx.x * TILES + t;
@@ -369,14 +356,11 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
         for (int q = 0; q < SSQ_LD; ++q) ssq_ld[q] = ((const f32x4_t*)p.ssq_in)[min(tid + q * NW * 64, n4 - 1)];   // chunk (= 4 batch columns) index & 3 is fixed per thread
     }
     // producer side: the old residual and gamma are requested up front as well (by every wave; wave 0 consumes them in the epilogue)
-    f32x4_t r_old[TILES], g_nx[TILES];
+    f32x4_t r_old = {0.f, 0.f, 0.f, 0.f}, g_nx = {0.f, 0.f, 0.f, 0.f};
     if constexpr (MODE == GV_RESIDNORM) {
-#pragma unroll
-        for (int t = 0; t < TILES; ++t) {
-            const int n0p = rb[t] * 16 + kg * 4;
-            r_old[t] = *(const f32x4_t*)(p.out + ((size_t)min(l15, p.B - 1) * p.ldo + n0p) * 4);
-            g_nx[t] = *(const f32x4_t*)(p.gamma + n0p);
-        }
+        const int n0p = blockIdx.x * 16 + kg * 4;
+        r_old = *(const f32x4_t*)(p.out + ((size_t)min(l15, p.B - 1) * p.ldo + n0p) * 4);
+        g_nx = *(const f32x4_t*)(p.gamma + n0p);
     }
     // x fragment (MFMA B operand: lane = batch column l15, 8 consecutive k): an MFMA tile has 16 batch columns; the lanes of the columns
     // >= B point outside the buffer descriptor, so they cost no request on the load path (with B = 8 half of every 1 KiB wave-load; the
@@ -394,33 +378,11 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
         // groups (64 columns) j_lo + w + NW * g, g = 0 .. : batch b holds g = b * PU .. b * PU + PU - 1.  Every batch but the last is complete
         // for every wave (the waves' group counts differ by at most one); in the last batch, entries past the end re-read the last valid
         // block (an L2 hit) against an all-zero x fragment, which adds exact zeros -- no predicated loads (predicated loads would make hipcc serialise the whole batch: a vmcnt(0) per load).
-        int kb_end = kblocks;
-        int j_end = (kb_end + 1) >> 1;                            // the last group may hold a single 32-block (16-bit weights; fp8 needs K % 64 == 0)
-        int j_lo = 0;
-        if constexpr (MODE == GV_RESIDNORM) {
-            if (p.ksplit > 1) {                                   // this workgroup's K range: groups [j_lo, j_end)
-                const int per = (j_end + p.ksplit - 1) / p.ksplit, part = (int)blockIdx.x % p.ksplit;
-                j_lo = part * per;
-                j_end = min(j_lo + per, j_end);
-                kb_end = min(2 * j_end, kblocks);
-            }
-        }
+        const int kb_end = kblocks;
+        const int j_end = (kb_end + 1) >> 1;                      // the last group may hold a single 32-block (16-bit weights; fp8 needs K % 64 == 0)
+        constexpr int j_lo = 0;
         const int gpw = (j_end - j_lo + NW - 1) / NW;
         const int nb = (gpw + PU - 1) / PU;
-        // K-order rotation (round 4): every workgroup multiplies the SAME activation vector, and with every workgroup starting at k = 0 the
-        // 32 - 80 workgroups of an XCD ask its L2 for the same few lines at the same moment -- the channel that holds them serves them one
-        // after the other while the other 15 idle (measured: 13B fp8 down_proj 22.0 us at 8 sequences against 16.2 us at one, where a wave-load
-        // of x is 1 line instead of 8; the bare weight stream takes 12.4).  Workgroup i (of its XCD) therefore starts its sweep `rot` rounds
-        // further into K and wraps around: at any moment the XCD's workgroups read x lines spread over the whole vector.  A wave still adds its
-        // groups in one fixed order -- a function of the workgroup index and K only, never of the batch or the weight type -- so results stay
-        // bitwise batch-invariant and the fp8 path keeps its bit-equality with the 16-bit path.
-        const int rot = p.rot ? (int)(blockIdx.x >> 3) % max(gpw, 1) : 0;
-        int r_last = gpw - 1 - rot; if (r_last < 0) r_last += gpw;      // the iteration that visits the physically last (possibly incomplete) round
-        auto group_of = [&](int r) -> int {                              // iteration r of this wave -> 64-column group; r >= gpw: the padding of the last batch
-            int pr = r + rot; if (pr >= gpw) pr -= gpw;
-            return r < gpw ? j_lo + w + NW * pr : j_end;
-        };
-        auto ragged = [&](int b) -> bool { return b == r_last / PU || (b + 1) * PU > gpw; };   // batch b needs the out-of-range masks
         using wreg_t = typename std::conditional<W8, u32x4_t, typename T::v8>::type;
         constexpr int WH = W8 ? 1 : 2;                            // weight loads per group and row block
         const char* wp[TILES];
@@ -431,7 +393,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
         auto load = [&](wreg_t (&wf)[PU][WH][TILES], typename T::v8 (&xf)[PU][XH], int b) {
 #pragma unroll
             for (int u = 0; u < PU; ++u) {
-                const int g = group_of(b * PU + u);
+                const int g = j_lo + w + NW * (b * PU + u);
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int kb = min(2 * g + h, kb_end - 1);
@@ -449,7 +411,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
         auto mma = [&](wreg_t (&wf)[PU][WH][TILES], typename T::v8 (&xf)[PU][XH], int b, bool last) {
 #pragma unroll
             for (int u = 0; u < PU; ++u) {
-                const int g = group_of(b * PU + u);
+                const int g = j_lo + w + NW * (b * PU + u);
                 typename T::v8 xv[2];
                 xv[0] = xf[u][0];
                 if constexpr (X2) {
@@ -480,20 +442,20 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
         for (; i + 2 < nb; i += 2) {
             load(wb, xb, i + 1);
             __builtin_amdgcn_sched_barrier(0);
-            mma(wa, xa, i, ragged(i));
+            mma(wa, xa, i, false);
             __builtin_amdgcn_sched_barrier(0);
             load(wa, xa, i + 2);
             __builtin_amdgcn_sched_barrier(0);
-            mma(wb, xb, i + 1, ragged(i + 1));
+            mma(wb, xb, i + 1, false);
             __builtin_amdgcn_sched_barrier(0);
         }
         if (nb - i == 2) {
             load(wb, xb, i + 1);
             __builtin_amdgcn_sched_barrier(0);
-            mma(wa, xa, i, ragged(i));
-            mma(wb, xb, i + 1, ragged(i + 1));
+            mma(wa, xa, i, false);
+            mma(wb, xb, i + 1, true);
         } else {
-            mma(wa, xa, i, ragged(i));
+            mma(wa, xa, i, true);
         }
     }
 #pragma unroll
@@ -541,49 +503,20 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
     }
     const int n0 = (MODE == GV_SWIGLU ? (int)blockIdx.x : rb[0]) * 16 + kg * 4;
     if constexpr (MODE == GV_RESIDNORM) {
-        if (p.ksplit > 1) {
-            // Cross-workgroup sum over the K ranges WITHOUT fences (same protocol as decode_attn_split_kernel): the partial tiles travel as
-            // agent-scope relaxed atomics (sc1: written through to / read from the memory side, coherent across the XCDs' L2s), the stores
-            // are acknowledged (vmcnt) before the ticket is taken, and the last arriver adds the parts in K order -- its own from memory too,
-            // so the sum does not depend on who arrives last -- then runs the epilogue and re-arms the ticket.
-            const int grp = (int)blockIdx.x / p.ksplit, part = (int)blockIdx.x % p.ksplit;
-            float* mine = p.kpart + (((size_t)grp * p.ksplit + part) * TILES) * 256 + lane * 4;
-#pragma unroll
-            for (int t = 0; t < TILES; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) __hip_atomic_store(mine + t * 256 + r, tot[t][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            unsigned tk = 0;
-            if (lane == 0) tk = __hip_atomic_fetch_add(p.kticket + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            tk = __builtin_amdgcn_readfirstlane(tk);
-            if (tk != (unsigned)p.ksplit - 1u) return;
-            if (lane == 0) __hip_atomic_store(p.kticket + grp, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const float* base = p.kpart + ((size_t)grp * p.ksplit * TILES) * 256 + lane * 4;
-#pragma unroll
-            for (int t = 0; t < TILES; ++t) {
-                f32x4_t a = {0.f, 0.f, 0.f, 0.f};
-                for (int ks = 0; ks < p.ksplit; ++ks)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) a[r] += __hip_atomic_load(base + ((size_t)ks * TILES + t) * 256 + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                tot[t] = a;
-            }
+        // r = resid + y (fp32, written back); xg = round16(r * gamma); sum of r^2 over this workgroup's 16 rows per batch column
+        float sq = 0.f;
+        if (b < p.B) {
+            f32x4_t* rp = (f32x4_t*)(p.out + ((size_t)b * p.ldo + n0) * 4);
+            const f32x4_t r = r_old + tot[0];
+            *rp = r;
+            const f32x4_t g = g_nx;
+            *(u32x2_t*)(p.xg + ((size_t)b * p.ldo + n0) * 2) = pack4<T>(r[0] * g[0], r[1] * g[1], r[2] * g[2], r[3] * g[3]);
+            sq = (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
         }
-        // r = resid + y (fp32, written back); xg = round16(r * gamma); sum of r^2 over each row block's 16 rows per batch column
-#pragma unroll
-        for (int t = 0; t < TILES; ++t) {
-            const int n0t = rb[t] * 16 + kg * 4;
-            float sq = 0.f;
-            if (b < p.B) {
-                f32x4_t* rp = (f32x4_t*)(p.out + ((size_t)b * p.ldo + n0t) * 4);
-                const f32x4_t r = r_old[t] + tot[t];
-                *rp = r;
-                const f32x4_t g = g_nx[t];
-                *(u32x2_t*)(p.xg + ((size_t)b * p.ldo + n0t) * 2) = pack4<T>(r[0] * g[0], r[1] * g[1], r[2] * g[2], r[3] * g[3]);
-                sq = (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
-            }
-            sq = rows_sum_to_row3(sq);               // sum over the four rows of 16 lanes (the 16 output rows of the block) without LDS round trips
-            if (kg == 3) p.ssq_out[(size_t)rb[t] * 16 + b] = sq;                   // columns >= B carry 0
+        {   // sum over the four rows of 16 lanes (the 16 output rows of this workgroup) without LDS round trips
+            sq = rows_sum_to_row3(sq);
         }
+        if (kg == 3) p.ssq_out[(size_t)blockIdx.x * 16 + b] = sq;               // columns >= B carry 0
         return;
     }
     if constexpr (MODE == GV_F32) {
@@ -601,13 +534,10 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
     }
     if (b >= p.B) return;
     if constexpr (MODE == GV_SWIGLU) {
+        float v[4];
 #pragma unroll
-        for (int q = 0; q < TILES / 2; ++q) {
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { const float g = tot[2 * q][r]; v[r] = g * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(g * -1.4426950408889634f)) * tot[2 * q + 1][r]; }   // same SiLU as gemm.hip
-            *(u32x2_t*)(p.out + ((size_t)b * p.ldo + ((int)blockIdx.x * (TILES / 2) + q) * 16 + kg * 4) * 2) = pack4<T>(v[0], v[1], v[2], v[3]);
-        }
+        for (int r = 0; r < 4; ++r) { const float g = tot[0][r]; v[r] = g * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(g * -1.4426950408889634f)) * tot[1][r]; }   // same SiLU as gemm.hip
+        *(u32x2_t*)(p.out + ((size_t)b * p.ldo + n0) * 2) = pack4<T>(v[0], v[1], v[2], v[3]);
     } else if constexpr (MODE == GV_STORE16) {
 #pragma unroll
         for (int t = 0; t < TILES; ++t)
@@ -1252,10 +1182,7 @@ int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void
     GemvArgs a;
     a.W = (const char*)W; a.x = (const char*)x; a.out = (char*)out; a.N = N; a.K = K; a.B = B; a.ldx = ldx; a.ldo = ldo; a.wscale = wscale;
     a.ssq_in = nullptr; a.nparts_in = 0; a.inv_h = 0.f; a.eps = 0.f; a.gamma = nullptr; a.xg = nullptr; a.ssq_out = nullptr; a.amax_val = nullptr; a.amax_idx = nullptr;
-    a.ksplit = 1; a.kpart = nullptr; a.kticket = nullptr;
-    { static int rot = -1; if (rot < 0) { const char* e = getenv("PGV_GEMV_ROT"); rot = (e && e[0] == '0') ? 0 : 1; } a.rot = rot; }
     if (norm) {
-        a.kpart = norm->kpart; a.kticket = norm->kticket;
         a.ssq_in = norm->ssq_in; a.nparts_in = norm->nparts_in; a.inv_h = 1.0f / (float)norm->hidden; a.eps = norm->eps;
         a.gamma = norm->gamma; a.xg = (char*)norm->xg; a.ssq_out = norm->ssq_out; a.amax_val = norm->amax_val; a.amax_idx = norm->amax_idx;
         PGV_CHECK(norm->nparts_in * 4 <= 3 * 8 * 64, "gemv: %d sum-of-squares partials exceed what a consumer workgroup loads (hidden <= 6144)", norm->nparts_in);
@@ -1281,36 +1208,15 @@ int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void
     switch (mode) {
         case GV_STORE16:
             // three row blocks per workgroup when that puts at most ~one workgroup on every CU and nothing is left over (7B qkv: 768 -> 256)
-            // (13B: 960 -> 320 workgroups, two resident per CU -- with fp8 weights a 16-row workgroup moves as many activation lines as weight lines)
+            // (13B: 960 -> 320 workgroups, two resident per CU: with fp8 weights a 16-row workgroup requests as many activation lines as weight
+            // lines -- qkv 20.7 -> 18.7 us in the chain lab, gpurun_out/r4e)
             if (tl3 && grid % 3 == 0 && grid / 3 <= 2 * ctx->num_cu && grid / 3 >= ctx->num_cu / 2) PGV_GEMV(GV_STORE16, 8, 3, 1, 2, 2, grid / 3);
             else PGV_GEMV(GV_STORE16, 8, 1, 2, 4, 4, grid);
             break;
         case GV_RESID: PGV_GEMV(GV_RESID, 8, 1, 2, 4, 4, grid); break;
-        case GV_SWIGLU: {
-            // fp8 weights: two (gate, up) pairs per workgroup share the activation fragments (half the x lines; same K partition, same bits)
-            static int pairs = -1;
-            if (pairs < 0) { const char* e = getenv("PGV_GEMV_GU_PAIRS"); pairs = e ? atoi(e) : 1; }
-            if (w8 && pairs == 2 && grid % 2 == 0) PGV_GEMV(GV_SWIGLU, 8, 4, 1, 1, 1, grid / 2);
-            else PGV_GEMV(GV_SWIGLU, 8, 2, 1, 2, 2, grid);
-            break;
-        }
+        case GV_SWIGLU: PGV_GEMV(GV_SWIGLU, 8, 2, 1, 2, 2, grid); break;
         case GV_F32: PGV_GEMV(GV_F32, 8, 1, 2, 4, 4, grid); break;
-        case GV_RESIDNORM: {
-            // TL row blocks x TL K ranges per 16 TL rows: the same number of workgroups as the 16-row form, 1 / TL of its activation lines.
-            // The cut is a function of (N, K) alone -- never of the batch or the weight type -- so results stay bitwise batch-invariant and
-            // the fp8 path keeps its bit-equality with the 16-bit path.  PGV_GEMV_PROD_TL=1/2/4 forces a value (A/B).
-            static int forced = -1;
-            if (forced < 0) { const char* e = getenv("PGV_GEMV_PROD_TL"); forced = e ? atoi(e) : 0; }
-            const bool is_forced = (forced == 1 || forced == 2 || forced == 4);
-            int tl = is_forced ? forced : 1;
-            const int min_groups = is_forced ? 1 : 16;                // per K range: at least two 64-column groups per wave unless a test forces the cut
-            while (tl > 1 && (!a.kpart || !a.kticket || grid % tl != 0 || (K / 64) / tl < min_groups)) tl >>= 1;
-            a.ksplit = tl;
-            if (tl == 4) PGV_GEMV(GV_RESIDNORM, 8, 4, 1, 2, 2, grid);
-            else if (tl == 2) PGV_GEMV(GV_RESIDNORM, 8, 2, 1, 2, 2, grid);
-            else PGV_GEMV(GV_RESIDNORM, 8, 1, 2, 4, 4, grid);
-            break;
-        }
+        case GV_RESIDNORM: PGV_GEMV(GV_RESIDNORM, 8, 1, 2, 4, 4, grid); break;
         default: pgv_set_error("gemv: bad mode %d", mode); return PGV_EINVAL;
     }
 #undef PGV_GEMV
@@ -1322,13 +1228,17 @@ int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void
 // Workgroups per (sequence, head) unit.  The split is a function of the MODEL (its head count), never of the batch: a sequence's attention is
 // then computed with the same partition and the same merge order whether it is decoded alone or next to 15 others -- results stay bitwise
 // batch-invariant (tests/test_gpu_llm.py).  Head counts whose 8-sequence launch fills the chip's CUs in whole rounds (7B: 32 heads x 8 = 256)
-// keep the unsplit kernel; the others (13B: 40 heads -> 320 units = 1 1/4 rounds) are cut in 4 (1280 workgroups = 5 whole rounds).
-// PGV_DATTN_SPLIT=1/2/4/8 forces a value (A/B; bitwise invariance then holds only among runs with the same setting).
+// keep the unsplit kernel; the others (13B: 40 heads -> 320 units = 1 1/4 rounds) are cut in 2 (640 workgroups, all resident at once).
+// Measured (gpurun_out/r4d, 13B fp8, 8 sequences, us per layer): unsplit 18.7, 2 parts 18.1, 4 parts 22.6, 8 parts 31.4 -- 7B (256 units):
+// 12.8 / 14.2 / 18.8 / 26.4.  Every extra hand-off through the memory side (write-through stores -> acknowledged -> ticket -> loads) adds
+// ~4 us to a workgroup's life, which more resident workgroups only partly hide: a cut in 2 is the only one that pays, and only where the
+// unsplit launch leaves a ragged round.  PGV_DATTN_SPLIT=1/2/4/8 forces a value (A/B and the parity tests of every variant; bitwise
+// invariance then holds only among runs with the same setting).
 static int decode_attn_split(int heads, int num_cu) {
     static int forced = -1;
     if (forced < 0) { const char* e = getenv("PGV_DATTN_SPLIT"); forced = e ? atoi(e) : 0; }
     if (forced == 1 || forced == 2 || forced == 4 || forced == 8) return forced;
-    return (heads * 8) % num_cu == 0 ? 1 : 4;
+    return (heads * 8) % num_cu == 0 ? 1 : 2;
 }
 
 int pgv_launch_decode_attn(pgv_ctx* ctx, int dtype, const void* qkv, const int* pos, const void* rope, void* Kc, void* Vc, void* out, int B, int H,

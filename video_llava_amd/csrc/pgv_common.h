@@ -181,5 +181,4 @@ struct GemvNorm {
     const float* ssq_in = nullptr; int nparts_in = 0; int hidden = 1; float eps = 0.f;
     const float* gamma = nullptr; void* xg = nullptr; float* ssq_out = nullptr;
     float* amax_val = nullptr; int* amax_idx = nullptr;      // f32 mode: per-workgroup greedy candidates [ceil(N / 16)][16]
-    float* kpart = nullptr; unsigned* kticket = nullptr;     // producer mode: scratch of the K-split form ([N / 16][4][256] floats, [N / 16] tickets, zero); null = 16-row form
 };
