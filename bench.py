@@ -953,7 +953,8 @@ def main():
             del model, tower, frames
             side = {}
             for key, ov, st, wu, roof in (("fp16", {"dtype": "fp16"}, 5, 1, False),
-                                          ("cfg5_13b_fp8", {"llm": "13b", "weights": "fp8"}, 3, 1, True)):
+                                          ("cfg5_13b_fp8", {"llm": "13b", "weights": "fp8"}, 3, 1, True),
+                                          ("clips32", {"clips_per_gpu": 32}, 2, 1, False)):     # what a long runner queue would use: the weight stream of a token step shared by 32 clips
                 try:
                     side[key] = side_line(args, dev, ov, st, wu, roof)
                 except Exception as e:                           # noqa: BLE001

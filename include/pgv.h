@@ -219,7 +219,7 @@ int pgv_gemm(pgv_ctx *ctx, int dtype, int epi, const void *d_A, int lda, const v
 /* CLIP self-attention on a fused qkv buffer [T*N, 3C] (q | k | v column blocks) -> [T*N, C]; head_dim 64, no mask
  * (HF CLIPAttention eager math, HF:clip/modeling_clip.py:259-277). */
 int pgv_vit_attention(pgv_ctx *ctx, int dtype, const void *d_qkv, void *d_out, int T, int N, int C, int heads, void *stream);
-/* Decode-time projection y[B,N] = x[B,K] W[N,K]^T for B <= 16 (weights streamed once).  mode: 0 = 16-bit out,
+/* Decode-time projection y[B,N] = x[B,K] W[N,K]^T for B <= 64 (weights streamed once; 16 sequences per MFMA column tile).  mode: 0 = 16-bit out,
  * 1 = fp32 residual accumulate, 2 = SwiGLU (W rows interleaved [32 gate | 32 up], out [B, N/2]), 3 = fp32 out.
  * d_W is in the fragment-blocked layout produced by pgv_pack_blocked (rows padded to a multiple of 16). */
 int pgv_gemv(pgv_ctx *ctx, int dtype, int mode, const void *d_W, const void *d_x, int ldx, void *d_out, int ldo, int N, int K,

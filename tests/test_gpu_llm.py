@@ -106,17 +106,18 @@ def test_ragged_batch_matches_single(ctx, golden_dir):
         assert singles[i] == ref
 
 
-@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 115, 116, 117])
 def test_ragged_batch_random_shapes(ctx, seed):
-    """Randomised version of the property above: 1..16 sequences, prompt lengths from a few tokens to several prefill-attention chunks
-    (64-key chunks, 128-query blocks), so prompts end on both sides of every tiling boundary; greedy tokens of the batch == single runs."""
+    """Randomised version of the property above: 1..16 sequences (seeds > 100: 17..64, the batches that span several MFMA column tiles),
+    prompt lengths from a few tokens to several prefill-attention chunks (64-key chunks, 128-query blocks), so prompts end on both sides of
+    every tiling boundary; greedy tokens of the batch == single runs."""
     cfg = synth.LLAMA_TINY
     w = synth.make_llama_weights(cfg, seed=3, head_std=0.08)
     m = _model(cfg, w, torch.float16)
     rng = np.random.default_rng(seed)
     PATCH, START, END = cfg.vocab - 3, cfg.vocab - 2, cfg.vocab - 1
     V = 20
-    B = int(rng.integers(1, 17))
+    B = int(rng.integers(1, 17)) if seed < 100 else int(rng.integers(17, 65))
     prompts, feats = [], []
     for b in range(B):
         head = rng.integers(1, cfg.vocab - 3, int(rng.integers(1, 260))).tolist()
@@ -282,7 +283,7 @@ def test_gemv_batch_columns_are_independent(ctx, dtype, mode, N, K):
     from video_llava_amd import _lib
     g = torch.Generator().manual_seed(N + K)
     w = (torch.randn(N, K, generator=g) * 0.05).to(dtype).to(DEV)
-    x = torch.randn(11, K, generator=g).to(dtype).to(DEV)
+    x = torch.randn(64, K, generator=g).to(dtype).to(DEV)
     dc = _lib.dtype_code(dtype)
     Np = (N + 15) // 16 * 16
     wb = torch.zeros(Np, K, dtype=dtype, device=DEV)
@@ -312,9 +313,21 @@ def test_gemv_batch_columns_are_independent(ctx, dtype, mode, N, K):
             _lib.check(ctx.lib.pgv_quantize_fp8_blocked(ctx.handle, dc, wb.data_ptr(), w8.data_ptr(), sc.data_ptr(), N, K, _lib.stream_ptr()))
         o8, o11, o1 = run(8, quantised), run(11, quantised), run(1, quantised)
         assert torch.equal(o8, o11[:8]) and torch.equal(o1, o11[:1]), (mode, N, K, quantised)
+        # batches beyond one MFMA tile (round 4): 2 / 4 column tiles of 16 sequences per weight fragment -- every tile is a separate pass of
+        # the 16-column arithmetic, so the rows shared with a narrower launch must stay bit-identical (17 and 33: a tile holding one sequence)
+        o16 = run(16, quantised)
+        assert torch.equal(o11, o16[:11])
+        for B in (17, 32, 33, 48, 64):
+            oB = run(B, quantised)
+            assert torch.equal(oB[:16], o16), (mode, N, K, quantised, B)
+            if B == 64:
+                o64 = oB
+        for B in (17, 32, 33, 48):
+            assert torch.equal(run(B, quantised), o64[:B]), (mode, N, K, quantised, B)
         if mode in (0, 3) and not quantised:
-            ref = x[:8].cpu().float() @ w.cpu().float().t()             # on the CPU: exact fp32 accumulation
-            assert rel(o8, ref) < (8e-3 if dtype == torch.bfloat16 else 1e-3)
+            ref = x.cpu().float() @ w.cpu().float().t()                 # on the CPU: exact fp32 accumulation
+            assert rel(o8, ref[:8]) < (8e-3 if dtype == torch.bfloat16 else 1e-3)
+            assert rel(o64, ref) < (8e-3 if dtype == torch.bfloat16 else 1e-3)
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 1e-3), (torch.bfloat16, 8e-3)])
@@ -384,6 +397,52 @@ def test_full_7b_batch_invariance(ctx, weights):
                 nxt, lg = m.decode_step(kv1, nxt, want_logits=True)
         del kv1
     assert torch.isfinite(steps_b[-1][1]).all()
+
+
+@pytest.mark.parametrize("B,weights", [(32, "bf16"), (64, "bf16"), (64, "fp8")])
+def test_full_7b_wide_batch_invariance(ctx, B, weights):
+    """Decode batches beyond 16: 32 and 64 sequences per token step share ONE pass over the weights (2 / 4 MFMA column tiles per
+    weight fragment).  At PG-Video-LLaVA-7B size (32 layers), ragged prompts with 356 video rows each: the logits of prefill + 5 decode steps
+    of sequences 0, 17, B / 2 + 3 and B - 1 inside the batch are BITWISE those of the same sequence decoded alone, and the device-side greedy
+    loop (pgv_llm_decode_greedy, graph-replayed) returns the same tokens as the stepwise path."""
+    from video_llava_amd import random_init as ri
+    from video_llava_amd.model.video_chatgpt import VideoChatGPTConfig, VideoChatGPTLlamaForCausalLM, VisionConfig
+    vocab = 32003
+    cfg = VideoChatGPTConfig(vocab_size=vocab, hidden_size=4096, intermediate_size=11008, num_hidden_layers=32, num_attention_heads=32, eos_token_id=None)
+    m = VideoChatGPTLlamaForCausalLM(cfg, VisionConfig(frame_size=224), torch.bfloat16, torch.device(DEV))
+    ri.load_streaming(m, ri.iter_llama_tensors(vocab=vocab, hidden=4096, inter=11008, layers=32, device=DEV, dtype=torch.bfloat16, seed=11))
+    vc = m.get_model().vision_config
+    vc.vid_patch_token, vc.vid_start_token, vc.vid_end_token, vc.use_vid_start_end = vocab - 3, vocab - 2, vocab - 1, True
+    if weights == "fp8":
+        m.quantize_weights_fp8()
+    rng = np.random.default_rng(2)
+    V = 356
+    prompts = [[1] + rng.integers(3, vocab - 3, 40 + int(rng.integers(0, 30))).tolist() + [vocab - 2] + [vocab - 3] * V + [vocab - 1]
+               + rng.integers(3, vocab - 3, 6).tolist() for _ in range(B)]
+    feats = torch.from_numpy(rng.standard_normal((B, V, 1024)).astype(np.float32) * 0.5).to(torch.float16).to(DEV)
+    n = 6
+    kv, nxt_b, lg_b = m.prefill(prompts, feats, 512, want_logits=True)
+    first = nxt_b.clone()
+    steps_b = [(nxt_b.clone(), lg_b.clone())]
+    for _ in range(n - 1):
+        nxt_b, lg_b = m.decode_step(kv, nxt_b, want_logits=True)
+        steps_b.append((nxt_b.clone(), lg_b.clone()))
+    assert torch.isfinite(steps_b[-1][1]).all()
+    # the chunked device-side loop on the same batch (eager first step, then hipGraph replays): same tokens as the stepwise path
+    kv, nxt2, _ = m.prefill(prompts, feats, 512)
+    assert torch.equal(nxt2, first)
+    toks = m.decode_greedy(kv, nxt2, n - 1)
+    for t in range(1, n):
+        assert torch.equal(toks[:, t - 1], steps_b[t][0]), t
+    del kv
+    for i in (0, 17, B // 2 + 3, B - 1):
+        kv1, nxt, lg = m.prefill([prompts[i]], feats[i:i + 1], 512, want_logits=True)
+        for t in range(n):
+            assert torch.equal(lg[0], steps_b[t][1][i]), (weights, B, i, t)
+            assert int(nxt[0]) == int(steps_b[t][0][i])
+            if t + 1 < n:
+                nxt, lg = m.decode_step(kv1, nxt, want_logits=True)
+        del kv1
 
 
 def test_greedy_pick_takes_the_first_index_on_ties(ctx):

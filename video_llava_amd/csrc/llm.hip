@@ -27,8 +27,9 @@ int pgv_launch_decode_attn(pgv_ctx* ctx, int dtype, const void* qkv, const int* 
 constexpr int kDattnSplitMax = 8, kDattnPart = 128 + 2;       // llm_kernels.hip: DSPLIT_MAX, DPART
 int pgv_launch_sample(const float* logits, int V, int B, float temperature, int top_k, const float* u, int u_stride, int u_by_step, int* next, int* pos,
                       int* step, int* hist, int hist_stride, int* done, int eos, int advance, hipStream_t s);
-int pgv_launch_argmax_parts(const float* val, const int* idx, int nblk, int V, int B, int* next, int* pos, int* step, int* hist, int hist_stride, int* done,
+int pgv_launch_argmax_parts(const float* val, const int* idx, int nblk, int amax_ts, int V, int B, int* next, int* pos, int* step, int* hist, int hist_stride, int* done,
                             int eos, int advance, hipStream_t s);
+constexpr int kMaxBatch = 64;        // decode GEMVs: up to 4 MFMA column tiles of 16 sequences per weight fragment
 enum { GV_STORE16 = 0, GV_RESID = 1, GV_SWIGLU = 2, GV_F32 = 3, GV_RESIDNORM = 5 };
 enum { AM_INC_POS = 1, AM_RECORD = 2, AM_SAMPLE = 4 };
 
@@ -69,8 +70,9 @@ struct pgv_kv {
     std::vector<void*> Kc, Vc;          // per layer [B][heads][max_seq][128]
     // fixed-address decode buffers (so a decode step can be captured into a hipGraph)
     float* resid; void* xn; void* qkv; void* ao; void* act; float* logits;
-    float* amax_val; int* amax_idx;     // greedy candidates of the lm_head GEMV: [vocab_cap / 16][16]
-    float* ssq;                         // sum-of-squares partials of the folded RMSNorm: [hidden / 16][16] (see GemvArgs in llm_kernels.hip)
+    float* amax_val; int* amax_idx;     // greedy candidates of the lm_head GEMV, tile-major: [ceil(B / 16)][vocab_cap / 16][16]
+    float* ssq;                         // sum-of-squares partials of the folded RMSNorm, tile-major: [ceil(B / 16)][hidden / 16][16] (see GemvArgs in llm_kernels.hip)
+    int ssq_ts, amax_ts;                // their tile strides in elements: hidden, vocab_cap
     float* dattn_part; unsigned* dattn_ticket;   // context-split decode attention: partial states [B * heads][8][130], arrival tickets [B * heads] (zero between launches)
     int *d_pos, *d_cur, *d_step, *d_done, *d_hist;
     std::vector<int> h_len;
@@ -289,17 +291,18 @@ extern "C" int pgv_llm_get_weight(pgv_ctx* ctx, pgv_llm* m, const char* name_in,
 // ---------------------------------------------------------------------------------------------
 extern "C" int pgv_kv_create(pgv_ctx* ctx, pgv_llm* llm, int batch, int max_seq, pgv_kv** out) {
     PGV_CHECK(ctx && llm && out, "pgv_kv_create: null argument");
-    PGV_CHECK(batch >= 1 && batch <= 16, "pgv_kv_create: batch %d outside [1,16] (decode GEMV tiles 16 sequences)", batch);
+    PGV_CHECK(batch >= 1 && batch <= kMaxBatch, "pgv_kv_create: batch %d outside [1,%d] (the decode GEMVs tile up to 4 x 16 sequences)", batch, kMaxBatch);
     PGV_CHECK(max_seq >= 1 && max_seq <= kMaxPos, "pgv_kv_create: max_seq %d outside [1,%d]", max_seq, kMaxPos);
     pgv_kv* kv = new pgv_kv();
     kv->llm = llm; kv->B = batch; kv->max_seq = max_seq;
     const size_t H = llm->cfg.hidden, I = llm->cfg.inter, V = llm->vocab_cap, L = llm->cfg.layers, B = batch;
     const size_t per = pgv_align(B * llm->cfg.heads * (size_t)max_seq * kHD * 2);
+    const size_t CTn = (B + 15) / 16;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += pgv_align(bytes); return o; };
     const size_t o_cache = take(per * 2 * L);
     const size_t o_resid = take(B * H * 4), o_xn = take(B * H * 2), o_qkv = take(B * 3 * H * 2), o_ao = take(B * H * 2), o_act = take(B * I * 2),
-                 o_logits = take(B * V * 4), o_ssq = take((H / 16) * 16 * 4), o_av = take((V / 16) * 16 * 4), o_ai = take((V / 16) * 16 * 4), o_ints = take((4 * B + B * (size_t)max_seq) * 4),
+                 o_logits = take(B * V * 4), o_ssq = take(CTn * H * 4), o_av = take(CTn * V * 4), o_ai = take(CTn * V * 4), o_ints = take((4 * B + B * (size_t)max_seq) * 4),
                  o_u = take(B * (size_t)max_seq * 4), o_dpart = take(B * llm->cfg.heads * (size_t)kDattnSplitMax * kDattnPart * 4), o_dtick = take(B * llm->cfg.heads * 4);
     hipError_t e = hipMalloc((void**)&kv->blob, off);
     if (e != hipSuccess) { delete kv; pgv_set_error("pgv_kv_create: hipMalloc(%zu MiB): %s", off >> 20, hipGetErrorString(e)); return PGV_ENOMEM; }
@@ -312,7 +315,8 @@ extern "C" int pgv_kv_create(pgv_ctx* ctx, pgv_llm* llm, int batch, int max_seq,
     kv->dattn_part = (float*)(b + o_dpart); kv->dattn_ticket = (unsigned*)(b + o_dtick);
     e = hipMemset(ints, 0, (4 * B + B * (size_t)max_seq) * 4);
     if (e == hipSuccess) e = hipMemset(kv->dattn_ticket, 0, B * llm->cfg.heads * 4);
-    if (e == hipSuccess) e = hipMemset(kv->ssq, 0, (H / 16) * 16 * 4);
+    if (e == hipSuccess) e = hipMemset(kv->ssq, 0, CTn * H * 4);
+    kv->ssq_ts = (int)H; kv->amax_ts = (int)V;
     if (e != hipSuccess) { (void)hipFree(kv->blob); delete kv; pgv_set_error("pgv_kv_create: memset: %s", hipGetErrorString(e)); return PGV_EHIP; }
     kv->h_len.assign(batch, 0);
     *out = kv;
@@ -345,6 +349,7 @@ static bool norm_fold_enabled() {
 static int lm_head_and_pick(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int B, int eos, int flags, hipStream_t s, int nparts) {
     const int H = m->cfg.hidden, V = m->cfg.vocab;
     GemvNorm nm; nm.ssq_in = nparts > 0 ? kv->ssq : nullptr; nm.nparts_in = nparts; nm.hidden = H; nm.eps = m->cfg.eps;     // nparts 0: kv->xn is already normalised
+    nm.ssq_ts = kv->ssq_ts; nm.amax_ts = kv->amax_ts;
     const bool greedy = !(flags & AM_SAMPLE);
     if (greedy) { nm.amax_val = kv->amax_val; nm.amax_idx = kv->amax_idx; }
     PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_F32, m->fp8 ? m->q_head : m->lm_head, kv->xn, H, kv->logits, V, V, H, B, s, m->fp8 ? m->s_head : nullptr, &nm));
@@ -353,7 +358,7 @@ static int lm_head_and_pick(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int B, int eos
         PGV_TRY(pgv_launch_sample(kv->logits, V, B, kv->s_temp, kv->s_topk, kv->d_u, B, 1, kv->d_cur, kv->d_pos, kv->d_step, kv->d_hist, kv->max_seq, kv->d_done,
                                   eos, flags & (AM_INC_POS | AM_RECORD), s));
     else
-        PGV_TRY(pgv_launch_argmax_parts(kv->amax_val, kv->amax_idx, (V + 15) / 16, V, B, kv->d_cur, kv->d_pos, kv->d_step, kv->d_hist, kv->max_seq, kv->d_done, eos,
+        PGV_TRY(pgv_launch_argmax_parts(kv->amax_val, kv->amax_idx, (V + 15) / 16, kv->amax_ts, V, B, kv->d_cur, kv->d_pos, kv->d_step, kv->d_hist, kv->max_seq, kv->d_done, eos,
                                         flags, s));
     pgv_prof_end(ctx, 6, s, 0.0, 0.0);
     return PGV_OK;
@@ -490,10 +495,10 @@ static int decode_enqueue(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int eos, int fla
     for (int li = 0; li < L; ++li) {
         const LlmLayer& l = m->layers[li];
         const bool q8 = m->fp8;
-        GemvNorm cons; cons.ssq_in = kv->ssq; cons.nparts_in = parts_in; cons.hidden = H; cons.eps = m->cfg.eps;
+        GemvNorm cons; cons.ssq_in = kv->ssq; cons.nparts_in = parts_in; cons.hidden = H; cons.eps = m->cfg.eps; cons.ssq_ts = kv->ssq_ts;
         PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_STORE16, q8 ? l.q_wqkv : l.wqkv, kv->xn, H, kv->qkv, 3 * H, 3 * H, H, B, s, q8 ? l.s_wqkv : nullptr, &cons));
         PGV_TRY(pgv_launch_decode_attn(ctx, m->dtype, kv->qkv, kv->d_pos, m->rope, kv->Kc[li], kv->Vc[li], kv->ao, B, H, heads, kv->max_seq, kv_bytes, s, kv->dattn_part, kv->dattn_ticket));
-        GemvNorm prod; prod.gamma = l.post_g; prod.xg = kv->xn; prod.ssq_out = kv->ssq;
+        GemvNorm prod; prod.gamma = l.post_g; prod.xg = kv->xn; prod.ssq_out = kv->ssq; prod.ssq_ts = kv->ssq_ts;
         PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_RESIDNORM, q8 ? l.q_wo : l.wo, kv->ao, H, kv->resid, H, H, H, B, s, q8 ? l.s_wo : nullptr, &prod));
         cons.nparts_in = nparts;
         PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_SWIGLU, q8 ? l.q_wgu : l.wgu, kv->xn, H, kv->act, I, 2 * I, H, B, s, q8 ? l.s_wgu : nullptr, &cons));

@@ -286,6 +286,9 @@ struct GemvArgs {
     // GV_F32 (lm_head): per-workgroup greedy candidates -- the largest logit of the workgroup's 16 rows and its (smallest) index per batch
     // column -- so the token pick scans N / 16 candidates instead of N logits (null: not wanted)
     float* amax_val; int* amax_idx;                            // [gridDim.x][16]
+    // batches beyond one MFMA tile (CT column tiles of 16 sequences, B <= 16 CT): every per-batch-column side array above is tile-major,
+    // [CT][...][16], with these tile strides in elements
+    int ssq_ts, amax_ts;
 };
 
 // W8 = true streams the fp8 (e4m3) blocked copy of the matrix: one 16-byte load per lane carries the A fragments of TWO consecutive
@@ -325,21 +328,29 @@ __device__ __forceinline__ typename T::v8 fp8x8_to_v8(unsigned lo, unsigned hi) 
 // the second MFMA.  (Columns >= 8 of either operand then hold the other half's data: they only reach output columns that are never stored.)
 // The activations are re-read from L2 by every workgroup: this halves their requests on the CU's load path and in the L2, which is what the
 // fp8 GEMVs (half the weight requests, the same x requests) were bound by: 3.5 -> 4.4 TB/s of fp8 bytes; 16-bit weights: +0.7 %.
-template <typename T, int MODE, bool W8, int NW, int TL, int PU, bool X2>
+// CT (round 4): column tiles of 16 sequences per weight fragment, B <= 16 CT (decode batches up to 64).  The weights are still streamed once;
+// every tile is a separate pass of the 16-column arithmetic (its own accumulators, its own sum-of-squares reduction, its own epilogue), so a
+// sequence's results are BITWISE the same whether it is decoded alone or next to 63 others.
+template <typename T, int MODE, bool W8, int NW, int TL, int PU, bool X2, int CT = 1>
 __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
     constexpr int TILES = TL;
-    __shared__ f32x4_t red[NW][TILES][64];
-    __shared__ f32x4_t ssq_red[NW][4];
+    static_assert(!X2 || CT == 1, "the merged x load uses the lanes of columns 8..15");
+    __shared__ f32x4_t red[NW][TILES * CT][64];
+    __shared__ f32x4_t ssq_red[NW][4 * CT];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kg = lane >> 4;
     const int kblocks = p.K >> 5;
     int rb[TILES];
     if constexpr (MODE == GV_SWIGLU) {
-        const int i0 = blockIdx.x * 16;                          // output column block
-        const int base = (i0 >> 5) * 64 + (i0 & 31);             // packed gate row (multiple of 16)
-        rb[0] = base >> 4;                                       // gate row block
-        rb[1] = (base + 32) >> 4;                                // matching up row block
+        static_assert(TILES % 2 == 0, "SwiGLU: (gate, up) row-block pairs");
+#pragma unroll
+        for (int q = 0; q < TILES / 2; ++q) {                    // TILES / 2 output column blocks per workgroup, each a (gate, up) pair of row blocks
+            const int i0 = ((int)blockIdx.x * (TILES / 2) + q) * 16;
+            const int base = (i0 >> 5) * 64 + (i0 & 31);         // packed gate row (multiple of 16)
+            rb[2 * q] = base >> 4;                               // gate row block
+            rb[2 * q + 1] = (base + 32) >> 4;                    // matching up row block
+        }
     } else {
 #pragma unroll
         for (int t = 0; t < TILES; ++t) rb[t] = blockIdx.x * TILES + t;
@@ -348,18 +359,21 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
     // (three independent loads whose first USE is after the weight loop: summing them here would park the wave on an L2 round trip
     // before its first weight load -- measured +1.4 us on the 18 us qkv GEMV)
     constexpr int SSQ_LD = 3;                                   // 3 x NW x 64 float4 >= 4 x hidden / 16 up to hidden 6144
-    f32x4_t ssq_ld[SSQ_LD];
+    f32x4_t ssq_ld[CT][SSQ_LD];
     const bool scaled = (MODE == GV_STORE16 || MODE == GV_SWIGLU || MODE == GV_F32) && p.ssq_in != nullptr;
     if (scaled) {
         const int n4 = p.nparts_in * 4;
 #pragma unroll
-        for (int q = 0; q < SSQ_LD; ++q) ssq_ld[q] = ((const f32x4_t*)p.ssq_in)[min(tid + q * NW * 64, n4 - 1)];   // chunk (= 4 batch columns) index & 3 is fixed per thread
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int q = 0; q < SSQ_LD; ++q) ssq_ld[ct][q] = ((const f32x4_t*)(p.ssq_in + (size_t)ct * p.ssq_ts))[min(tid + q * NW * 64, n4 - 1)];   // chunk (= 4 batch columns) index & 3 is fixed per thread
     }
     // producer side: the old residual and gamma are requested up front as well (by every wave; wave 0 consumes them in the epilogue)
-    f32x4_t r_old = {0.f, 0.f, 0.f, 0.f}, g_nx = {0.f, 0.f, 0.f, 0.f};
+    f32x4_t r_old[CT], g_nx = {0.f, 0.f, 0.f, 0.f};
     if constexpr (MODE == GV_RESIDNORM) {
         const int n0p = blockIdx.x * 16 + kg * 4;
-        r_old = *(const f32x4_t*)(p.out + ((size_t)min(l15, p.B - 1) * p.ldo + n0p) * 4);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) r_old[ct] = *(const f32x4_t*)(p.out + ((size_t)min(ct * 16 + l15, p.B - 1) * p.ldo + n0p) * 4);
         g_nx = *(const f32x4_t*)(p.gamma + n0p);
     }
     // x fragment (MFMA B operand: lane = batch column l15, 8 consecutive k): an MFMA tile has 16 batch columns; the lanes of the columns
@@ -367,13 +381,17 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
     // activations are re-read by every workgroup and the per-CU load path, not HBM, is what the fp8 GEMVs run into).  Their zeros only
     // feed output columns that are never stored.
     const __amdgpu_buffer_rsrc_t xrs = gv_make_rsrc(p.x, (unsigned)(((size_t)(p.B - 1) * p.ldx + p.K) * 2));
-    const unsigned xvo = l15 < p.B ? (unsigned)(((size_t)l15 * p.ldx + kg * 8) * 2) : 0x80000000u;
-    auto xload = [&](size_t kb) -> typename T::v8 {
-        return __builtin_bit_cast(typename T::v8, __builtin_amdgcn_raw_buffer_load_b128(xrs, xvo + (unsigned)(kb * 64), 0, 0));
-    };
-    f32x4_t acc[TILES];
+    unsigned xvo[CT];
 #pragma unroll
-    for (int t = 0; t < TILES; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int ct = 0; ct < CT; ++ct) xvo[ct] = ct * 16 + l15 < p.B ? (unsigned)(((size_t)(ct * 16 + l15) * p.ldx + kg * 8) * 2) : 0x80000000u;
+    auto xload = [&](size_t kb, int ct) -> typename T::v8 {
+        return __builtin_bit_cast(typename T::v8, __builtin_amdgcn_raw_buffer_load_b128(xrs, xvo[ct] + (unsigned)(kb * 64), 0, 0));
+    };
+    f32x4_t acc[TILES][CT];
+#pragma unroll
+    for (int t = 0; t < TILES; ++t)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) acc[t][ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     {
         // groups (64 columns) j_lo + w + NW * g, g = 0 .. : batch b holds g = b * PU .. b * PU + PU - 1.  Every batch but the last is complete
         // for every wave (the waves' group counts differ by at most one); in the last batch, entries past the end re-read the last valid
@@ -390,7 +408,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
         for (int t = 0; t < TILES; ++t) wp[t] = p.W + ((size_t)rb[t] * (W8 ? (p.K >> 6) : kblocks)) * 1024 + lane * 16;
         constexpr int XH = X2 ? 1 : 2;                            // x loads per group
         const unsigned xvo2 = (l15 & 7) < p.B ? (unsigned)(((size_t)(l15 & 7) * p.ldx + (l15 >> 3) * 32 + kg * 8) * 2) : 0x80000000u;
-        auto load = [&](wreg_t (&wf)[PU][WH][TILES], typename T::v8 (&xf)[PU][XH], int b) {
+        auto load = [&](wreg_t (&wf)[PU][WH][TILES], typename T::v8 (&xf)[PU][XH][CT], int b) {
 #pragma unroll
             for (int u = 0; u < PU; ++u) {
                 const int g = j_lo + w + NW * (b * PU + u);
@@ -402,41 +420,52 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
                         for (int t = 0; t < TILES; ++t)
                             wf[u][W8 ? 0 : h][t] = __builtin_nontemporal_load((const wreg_t*)(wp[t] + (size_t)(W8 ? min(g, j_end - 1) : kb) * 1024));
                     }
-                    if constexpr (!X2) xf[u][h] = xload((size_t)kb);
-                    else if (h == 0)
-                        xf[u][0] = __builtin_bit_cast(typename T::v8, __builtin_amdgcn_raw_buffer_load_b128(xrs, xvo2 + (unsigned)min(g, j_end - 1) * 128u, 0, 0));
+                    if constexpr (!X2) {
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct) xf[u][h][ct] = xload((size_t)kb, ct);
+                    } else if (h == 0)
+                        xf[u][0][0] = __builtin_bit_cast(typename T::v8, __builtin_amdgcn_raw_buffer_load_b128(xrs, xvo2 + (unsigned)min(g, j_end - 1) * 128u, 0, 0));
                 }
             }
         };
-        auto mma = [&](wreg_t (&wf)[PU][WH][TILES], typename T::v8 (&xf)[PU][XH], int b, bool last) {
+        auto mma = [&](wreg_t (&wf)[PU][WH][TILES], typename T::v8 (&xf)[PU][XH][CT], int b, bool last) {
 #pragma unroll
             for (int u = 0; u < PU; ++u) {
                 const int g = j_lo + w + NW * (b * PU + u);
-                typename T::v8 xv[2];
-                xv[0] = xf[u][0];
+                typename T::v8 xv[2][CT];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) xv[0][ct] = xf[u][0][ct];
                 if constexpr (X2) {
-                    const u32x4_t r = __builtin_bit_cast(u32x4_t, xf[u][0]);
+                    const u32x4_t r = __builtin_bit_cast(u32x4_t, xf[u][0][0]);
                     u32x4_t q;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) q[e] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)r[e], 0x128, 0xF, 0xF, true);   // row_ror:8
-                    xv[1] = __builtin_bit_cast(typename T::v8, q);
-                } else xv[1] = xf[u][XH - 1];
+                    xv[1][0] = __builtin_bit_cast(typename T::v8, q);
+                } else {
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) xv[1][ct] = xf[u][XH - 1][ct];
+                }
                 if (last) {
                     const typename T::v8 z = {};
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) xv[h] = (2 * g + h >= kb_end) ? z : xv[h];
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct) xv[h][ct] = (2 * g + h >= kb_end) ? z : xv[h][ct];
                 }
 #pragma unroll
                 for (int t = 0; t < TILES; ++t)
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        if constexpr (W8) acc[t] = T::mfma16(fp8x8_to_v8<T>(wf[u][0][t][2 * h], wf[u][0][t][2 * h + 1]), xv[h], acc[t]);
-                        else acc[t] = T::mfma16(wf[u][h][t], xv[h], acc[t]);
+                        typename T::v8 wv;
+                        if constexpr (W8) wv = fp8x8_to_v8<T>(wf[u][0][t][2 * h], wf[u][0][t][2 * h + 1]);      // widened once, used by every column tile
+                        else wv = wf[u][h][t];
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct) acc[t][ct] = T::mfma16(wv, xv[h][ct], acc[t][ct]);
                     }
             }
         };
         wreg_t wa[PU][WH][TILES], wb[PU][WH][TILES];
-        typename T::v8 xa[PU][XH], xb[PU][XH];
+        typename T::v8 xa[PU][XH][CT], xb[PU][XH][CT];
         load(wa, xa, 0);
         int i = 0;
         for (; i + 2 < nb; i += 2) {
@@ -459,13 +488,17 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
         }
     }
 #pragma unroll
-    for (int t = 0; t < TILES; ++t) red[w][t][lane] = acc[t];
+    for (int t = 0; t < TILES; ++t)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) red[w][t * CT + ct][lane] = acc[t][ct];
     if (scaled) {
-        const int n4 = p.nparts_in * 4;
+      const int n4 = p.nparts_in * 4;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
         f32x4_t ssq_acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < SSQ_LD; ++q)
-            if (tid + q * NW * 64 < n4) ssq_acc += ssq_ld[q];
+            if (tid + q * NW * 64 < n4) ssq_acc += ssq_ld[ct][q];
         // lanes with equal (lane & 3) hold the same 4 batch columns (NW * 64 is a multiple of 4): fold the wave, lanes 48..51 publish.  DPP rotations
         // inside the rows of 16 and the gfx950 row / half swaps across them: no LDS round trips (four dependent ds_bpermute rounds sat on the
         // tail of every consumer launch).  Fixed association per lane: deterministic.
@@ -476,27 +509,30 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
             v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));      // row_ror:8
             ssq_acc[e] = rows_sum_to_row3(v);
         }
-        if (lane >= 48 && lane < 52) ssq_red[w][lane - 48] = ssq_acc;
+        if (lane >= 48 && lane < 52) ssq_red[w][ct * 4 + lane - 48] = ssq_acc;
+      }
     }
     __syncthreads();
     if (w != 0) return;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {                             // one pass of the 16-column epilogue per column tile
     f32x4_t tot[TILES];
 #pragma unroll
     for (int t = 0; t < TILES; ++t) {
-        tot[t] = red[0][t][lane];
+        tot[t] = red[0][t * CT + ct][lane];
 #pragma unroll
-        for (int ww = 1; ww < NW; ++ww) tot[t] += red[ww][t][lane];
+        for (int ww = 1; ww < NW; ++ww) tot[t] += red[ww][t * CT + ct][lane];
     }
     if constexpr (W8) {                                           // per-row power-of-two scale: exact in fp32
 #pragma unroll
         for (int t = 0; t < TILES; ++t) tot[t] *= *(const f32x4_t*)(p.wscale + rb[t] * 16 + kg * 4);
     }
-    // lane holds D[n = kg*4 + r][b = l15]
-    const int b = l15;
+    // lane holds D[n = kg*4 + r][b = ct*16 + l15]
+    const int b = ct * 16 + l15;
     if (scaled) {
         float ss = 0.f;
 #pragma unroll
-        for (int ww = 0; ww < NW; ++ww) ss += ssq_red[ww][b >> 2][b & 3];       // fixed order: deterministic
+        for (int ww = 0; ww < NW; ++ww) ss += ssq_red[ww][ct * 4 + (l15 >> 2)][l15 & 3];       // fixed order: deterministic
         const float rstd = rsqrtf(ss * p.inv_h + p.eps);
 #pragma unroll
         for (int t = 0; t < TILES; ++t) tot[t] *= rstd;
@@ -507,7 +543,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
         float sq = 0.f;
         if (b < p.B) {
             f32x4_t* rp = (f32x4_t*)(p.out + ((size_t)b * p.ldo + n0) * 4);
-            const f32x4_t r = r_old + tot[0];
+            const f32x4_t r = r_old[ct] + tot[0];
             *rp = r;
             const f32x4_t g = g_nx;
             *(u32x2_t*)(p.xg + ((size_t)b * p.ldo + n0) * 2) = pack4<T>(r[0] * g[0], r[1] * g[1], r[2] * g[2], r[3] * g[3]);
@@ -516,8 +552,8 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
         {   // sum over the four rows of 16 lanes (the 16 output rows of this workgroup) without LDS round trips
             sq = rows_sum_to_row3(sq);
         }
-        if (kg == 3) p.ssq_out[(size_t)blockIdx.x * 16 + b] = sq;               // columns >= B carry 0
-        return;
+        if (kg == 3) p.ssq_out[(size_t)ct * p.ssq_ts + (size_t)blockIdx.x * 16 + l15] = sq;               // columns >= B carry 0
+        continue;
     }
     if constexpr (MODE == GV_F32) {
         if (p.amax_val != nullptr) {                              // wave-uniform
@@ -529,15 +565,18 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
                 const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
                 if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
             }
-            if (kg == 0) { p.amax_val[(size_t)blockIdx.x * 16 + b] = bv; p.amax_idx[(size_t)blockIdx.x * 16 + b] = bi; }
+            if (kg == 0) { p.amax_val[(size_t)ct * p.amax_ts + (size_t)blockIdx.x * 16 + l15] = bv; p.amax_idx[(size_t)ct * p.amax_ts + (size_t)blockIdx.x * 16 + l15] = bi; }
         }
     }
-    if (b >= p.B) return;
+    if (b >= p.B) continue;
     if constexpr (MODE == GV_SWIGLU) {
-        float v[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const float g = tot[0][r]; v[r] = g * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(g * -1.4426950408889634f)) * tot[1][r]; }   // same SiLU as gemm.hip
-        *(u32x2_t*)(p.out + ((size_t)b * p.ldo + n0) * 2) = pack4<T>(v[0], v[1], v[2], v[3]);
+        for (int q = 0; q < TILES / 2; ++q) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float g = tot[2 * q][r]; v[r] = g * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(g * -1.4426950408889634f)) * tot[2 * q + 1][r]; }   // same SiLU as gemm.hip
+            *(u32x2_t*)(p.out + ((size_t)b * p.ldo + ((int)blockIdx.x * (TILES / 2) + q) * 16 + kg * 4) * 2) = pack4<T>(v[0], v[1], v[2], v[3]);
+        }
     } else if constexpr (MODE == GV_STORE16) {
 #pragma unroll
         for (int t = 0; t < TILES; ++t)
@@ -551,13 +590,14 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
         for (int r = 0; r < 4; ++r)
             if (n0 + r < p.N) op[r] = tot[0][r];
     }
+    }   // column tiles
 }
 
 // decode: resid[b] = embed[tok[b]] plus the producer side of the folded RMSNorm (see GemvArgs): xg = round16(resid * gamma of layer 0's
 // input norm), ssq[0][b] = sum resid^2 (one partial per sequence).
 template <typename T>
 __global__ __launch_bounds__(256) void embed_tok_norm_kernel(const int* __restrict__ tok, const typename T::elem* __restrict__ embed, float* __restrict__ resid,
-                                                             const float* __restrict__ gamma, typename T::elem* __restrict__ xg, float* __restrict__ ssq, int H) {
+                                                             const float* __restrict__ gamma, typename T::elem* __restrict__ xg, float* __restrict__ ssq, int H, int ssq_ts) {
     __shared__ float red[4];
     const int b = blockIdx.x;
     const typename T::elem* p = embed + (size_t)tok[b] * H;
@@ -578,14 +618,14 @@ __global__ __launch_bounds__(256) void embed_tok_norm_kernel(const int* __restri
     ss = wave_sum(ss);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
     __syncthreads();
-    if (threadIdx.x == 0) ssq[b] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0) ssq[(size_t)(b >> 4) * ssq_ts + (b & 15)] = (red[0] + red[1]) + (red[2] + red[3]);     // tile-major [B / 16][...][16]
 }
 
 // Producer side of the folded RMSNorm for rows that already sit in the fp32 residual (the last prompt position of every sequence
 // before lm_head): xg = round16(resid * gamma), ssq[b] = sum resid^2.  One workgroup per row.
 template <typename T>
 __global__ __launch_bounds__(256) void resid_norm_prep_kernel(const float* __restrict__ resid, const float* __restrict__ gamma, typename T::elem* __restrict__ xg,
-                                                              float* __restrict__ ssq, int H) {
+                                                              float* __restrict__ ssq, int H, int ssq_ts) {
     __shared__ float red[4];
     const int b = blockIdx.x;
     float ss = 0.f;
@@ -597,7 +637,7 @@ __global__ __launch_bounds__(256) void resid_norm_prep_kernel(const float* __res
     ss = wave_sum(ss);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
     __syncthreads();
-    if (threadIdx.x == 0) ssq[b] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0) ssq[(size_t)(b >> 4) * ssq_ts + (b & 15)] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -936,7 +976,7 @@ __global__ __launch_bounds__(512) void decode_attn_split_kernel(const typename T
 // ---------------------------------------------------------------------------------------------
 // greedy pick from the lm_head GEMV's per-workgroup candidates (GemvArgs::amax_*): same result as a scan of the full logits
 // (largest value, smallest index on ties, NaN never), 16x fewer values to scan.
-__global__ __launch_bounds__(256) void argmax_parts_kernel(const float* __restrict__ val, const int* __restrict__ idx, int nblk, int V, int* __restrict__ next,
+__global__ __launch_bounds__(256) void argmax_parts_kernel(const float* __restrict__ val, const int* __restrict__ idx, int nblk, int amax_ts, int V, int* __restrict__ next,
                                                            int* __restrict__ pos, int* __restrict__ step, int* __restrict__ hist, int hist_stride,
                                                            int* __restrict__ done, int eos, int advance) {
     __shared__ float sv[4];
@@ -944,9 +984,10 @@ __global__ __launch_bounds__(256) void argmax_parts_kernel(const float* __restri
     const int b = blockIdx.x, tid = threadIdx.x;
     float best = -INFINITY;
     int bi = 0x7fffffff;
+    val += (size_t)(b >> 4) * amax_ts; idx += (size_t)(b >> 4) * amax_ts;          // tile-major [B / 16][nblk][16]
     for (int i = tid; i < nblk; i += 256) {
-        const float v = val[(size_t)i * 16 + b];
-        const int j = idx[(size_t)i * 16 + b];
+        const float v = val[(size_t)i * 16 + (b & 15)];
+        const int j = idx[(size_t)i * 16 + (b & 15)];
         if (v > best || (v == best && j < bi)) { best = v; bi = j; }
     }
 #pragma unroll
@@ -1163,26 +1204,29 @@ int pgv_launch_prefill_attn(pgv_ctx* ctx, int dtype, const void* qkv, void* out,
 
 int pgv_launch_final_prep(int dtype, const float* resid, const float* gamma, void* xg, float* ssq, int B, int H, hipStream_t s) {
     PGV_CHECK(H % 4 == 0, "final_prep: hidden %d unsupported", H);
-    PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((resid_norm_prep_kernel<T>), dim3(B), dim3(256), 0, s, resid, gamma, (typename T::elem*)xg, ssq, H));
+    PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((resid_norm_prep_kernel<T>), dim3(B), dim3(256), 0, s, resid, gamma, (typename T::elem*)xg, ssq, H, H));
     return PGV_OK;
 }
 
 int pgv_launch_embed_tok_norm(int dtype, const int* tok, const void* embed, float* resid, const float* gamma, void* xg, float* ssq, int B, int H, hipStream_t s) {
     PGV_CHECK(H % 8 == 0, "embed: hidden must be a multiple of 8");
     PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((embed_tok_norm_kernel<T>), dim3(B), dim3(256), 0, s, tok, (const typename T::elem*)embed, resid, gamma,
-                                                    (typename T::elem*)xg, ssq, H));
+                                                    (typename T::elem*)xg, ssq, H, H));
     return PGV_OK;
 }
 
 int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void* x, int ldx, void* out, int ldo, int N, int K, int B, hipStream_t s,
                     const float* wscale, const GemvNorm* norm) {
-    PGV_CHECK(B >= 1 && B <= 16, "gemv: batch %d outside [1,16]", B);
+    PGV_CHECK(B >= 1 && B <= 64, "gemv: batch %d outside [1,64]", B);
     PGV_CHECK(K % 32 == 0, "gemv: K=%d must be a multiple of 32", K);
     const bool w8 = wscale != nullptr;                  // W is the fp8 blocked copy (fp8.hip) with per-row scales
     GemvArgs a;
     a.W = (const char*)W; a.x = (const char*)x; a.out = (char*)out; a.N = N; a.K = K; a.B = B; a.ldx = ldx; a.ldo = ldo; a.wscale = wscale;
     a.ssq_in = nullptr; a.nparts_in = 0; a.inv_h = 0.f; a.eps = 0.f; a.gamma = nullptr; a.xg = nullptr; a.ssq_out = nullptr; a.amax_val = nullptr; a.amax_idx = nullptr;
+    a.ssq_ts = 0; a.amax_ts = 0;
+    PGV_CHECK(B <= 16 || norm == nullptr || (norm->ssq_ts > 0 && (norm->amax_val == nullptr || norm->amax_ts > 0)), "gemv: batches beyond 16 need the tile strides of the side arrays");
     if (norm) {
+        a.ssq_ts = norm->ssq_ts; a.amax_ts = norm->amax_ts;
         a.ssq_in = norm->ssq_in; a.nparts_in = norm->nparts_in; a.inv_h = 1.0f / (float)norm->hidden; a.eps = norm->eps;
         a.gamma = norm->gamma; a.xg = (char*)norm->xg; a.ssq_out = norm->ssq_out; a.amax_val = norm->amax_val; a.amax_idx = norm->amax_idx;
         PGV_CHECK(norm->nparts_in * 4 <= 3 * 8 * 64, "gemv: %d sum-of-squares partials exceed what a consumer workgroup loads (hidden <= 6144)", norm->nparts_in);
@@ -1201,6 +1245,25 @@ int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void
         else PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gemv_mfma_kernel<T, MODE_, false, NW_, TL_, PU16_, X2_>), dim3(GRID_), dim3(NW_ * 64), 0, s, a)); } while (0)
 #define PGV_GEMV(MODE_, NW_, TL_, PU16_, PU8X_, PU8_, GRID_) do { \
         if (x2) PGV_GEMV_X(MODE_, NW_, TL_, PU16_, PU8X_, true, GRID_); else PGV_GEMV_X(MODE_, NW_, TL_, PU16_, PU8_, false, GRID_); } while (0)
+    // batches beyond one MFMA tile: CT column tiles per weight fragment, one 64-column group per register buffer, no merged x load
+#define PGV_GEMV_W(MODE_, TL_, CT_, GRID_) do { \
+        if (w8) PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gemv_mfma_kernel<T, MODE_, true, 8, TL_, 1, false, CT_>), dim3(GRID_), dim3(512), 0, s, a)); \
+        else PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gemv_mfma_kernel<T, MODE_, false, 8, TL_, 1, false, CT_>), dim3(GRID_), dim3(512), 0, s, a)); } while (0)
+#define PGV_GEMV_WIDE(MODE_, TL_, GRID_) do { if (B <= 32) PGV_GEMV_W(MODE_, TL_, 2, GRID_); else PGV_GEMV_W(MODE_, TL_, 4, GRID_); } while (0)
+    if (B > 16) {
+        // Wide batches re-read 2 - 4 x the activation lines per workgroup, so the row blocks that share them matter more: qkv 3, gate/up two
+        // (gate, up) pairs when the block counts divide.  Same K partition and reduction order as the narrow kernels: same bits per column.
+        switch (mode) {
+            case GV_STORE16: if (grid % 3 == 0) PGV_GEMV_WIDE(GV_STORE16, 3, grid / 3); else PGV_GEMV_WIDE(GV_STORE16, 1, grid); break;
+            case GV_RESID: PGV_GEMV_WIDE(GV_RESID, 1, grid); break;
+            case GV_SWIGLU: if (grid % 2 == 0 && B <= 32) PGV_GEMV_W(GV_SWIGLU, 4, 2, grid / 2); else PGV_GEMV_WIDE(GV_SWIGLU, 2, grid); break;
+            case GV_F32: PGV_GEMV_WIDE(GV_F32, 1, grid); break;
+            case GV_RESIDNORM: PGV_GEMV_WIDE(GV_RESIDNORM, 1, grid); break;
+            default: pgv_set_error("gemv: bad mode %d", mode); return PGV_EINVAL;
+        }
+        pgv_prof_end(ctx, 3, s, 2.0 * B * (double)N * K, (w8 ? 1.0 : 2.0) * (double)N * K);
+        return PGV_OK;
+    }
     static int tl3 = -1, x2env = -1;
     if (tl3 < 0) { const char* e = getenv("PGV_GEMV_TL3"); tl3 = (e && e[0] == '0') ? 0 : 1; }
     if (x2env < 0) { const char* e = getenv("PGV_GEMV_X2"); x2env = (e && e[0] == '0') ? 0 : 1; }
@@ -1221,6 +1284,8 @@ int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void
     }
 #undef PGV_GEMV
 #undef PGV_GEMV_X
+#undef PGV_GEMV_WIDE
+#undef PGV_GEMV_W
     pgv_prof_end(ctx, 3, s, 2.0 * B * (double)N * K, (w8 ? 1.0 : 2.0) * (double)N * K);
     return PGV_OK;
 }
@@ -1268,9 +1333,9 @@ int pgv_launch_decode_attn(pgv_ctx* ctx, int dtype, const void* qkv, const int* 
     return PGV_OK;
 }
 
-int pgv_launch_argmax_parts(const float* val, const int* idx, int nblk, int V, int B, int* next, int* pos, int* step, int* hist, int hist_stride, int* done,
+int pgv_launch_argmax_parts(const float* val, const int* idx, int nblk, int amax_ts, int V, int B, int* next, int* pos, int* step, int* hist, int hist_stride, int* done,
                             int eos, int advance, hipStream_t s) {
-    hipLaunchKernelGGL(argmax_parts_kernel, dim3(B), dim3(256), 0, s, val, idx, nblk, V, next, pos, step, hist, hist_stride, done, eos, advance);
+    hipLaunchKernelGGL(argmax_parts_kernel, dim3(B), dim3(256), 0, s, val, idx, nblk, amax_ts, V, next, pos, step, hist, hist_stride, done, eos, advance);
     return PGV_OK;
 }
 

@@ -181,4 +181,5 @@ struct GemvNorm {
     const float* ssq_in = nullptr; int nparts_in = 0; int hidden = 1; float eps = 0.f;
     const float* gamma = nullptr; void* xg = nullptr; float* ssq_out = nullptr;
     float* amax_val = nullptr; int* amax_idx = nullptr;      // f32 mode: per-workgroup greedy candidates [ceil(N / 16)][16]
+    int ssq_ts = 0, amax_ts = 0;                             // batches beyond 16: the side arrays are tile-major [B / 16][...][16] with these tile strides (elements)
 };
