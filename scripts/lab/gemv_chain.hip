@@ -79,15 +79,15 @@ int main() {
     const int NM = 24;
     const size_t slot = (size_t)32016 * 4096 * 2;            // largest matrix (lm_head)
     char* W; CK(hipMalloc(&W, slot * NM)); CK(hipMemset(W, 0x11, slot * NM));     // small finite 16-bit values
-    char* x; CK(hipMalloc(&x, 16 * 11008 * 2)); CK(hipMemset(x, 0x11, 16 * 11008 * 2));
-    char* out; CK(hipMalloc(&out, 16 * 32016 * 4)); CK(hipMemset(out, 0, 16 * 32016 * 4));
+    char* x; CK(hipMalloc(&x, 64 * 11008 * 2)); CK(hipMemset(x, 0x11, 64 * 11008 * 2));
+    char* out; CK(hipMalloc(&out, 64 * 32016 * 4)); CK(hipMemset(out, 0, 64 * 32016 * 4));
     float* side; CK(hipMalloc(&side, 4096 * 4)); CK(hipMemset(side, 0, 4096 * 4));
     struct { const char* name; int mode, N, K; } cases[] = {{"qkv      (mode 0, 12288x4096)", 0, 12288, 4096}, {"gate/up  (mode 2, 22016x4096)", 2, 22016, 4096},
                                                             {"down     (mode 1, 4096x11008)", 1, 4096, 11008}, {"o_proj   (mode 1, 4096x4096)", 1, 4096, 4096},
                                                             {"lm_head  (mode 3, 32003x4096)", 3, 32003, 4096}};
     for (auto& c : cases) {
         const double bytes = 2.0 * ((c.N + 15) / 16 * 16) * c.K;
-        for (int B : {8, 1}) {
+        for (int B : {8, 16, 32, 64}) {
             char nm[96]; snprintf(nm, sizeof nm, "%s B=%d", c.name, B);
             time_chain(nm, s, NM, bytes, [&](int m) {
                 PK(pgv_gemv(ctx, PGV_BF16, c.mode, W + slot * m, x, c.K, out, c.mode == 2 ? c.N / 2 : c.N, c.N, c.K, B, s));

@@ -297,7 +297,7 @@ extern "C" int pgv_kv_create(pgv_ctx* ctx, pgv_llm* llm, int batch, int max_seq,
     kv->llm = llm; kv->B = batch; kv->max_seq = max_seq;
     const size_t H = llm->cfg.hidden, I = llm->cfg.inter, V = llm->vocab_cap, L = llm->cfg.layers, B = batch;
     const size_t per = pgv_align(B * llm->cfg.heads * (size_t)max_seq * kHD * 2);
-    const size_t CTn = (B + 15) / 16;
+    const size_t CTn = B <= 16 ? 1 : (B <= 32 ? 2 : 4);      // column tiles the decode GEMVs run with (1 / 2 / 4): every tile's slice of the side arrays is written, also the empty ones
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += pgv_align(bytes); return o; };
     const size_t o_cache = take(per * 2 * L);

@@ -1256,7 +1256,7 @@ int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void
         switch (mode) {
             case GV_STORE16: if (grid % 3 == 0) PGV_GEMV_WIDE(GV_STORE16, 3, grid / 3); else PGV_GEMV_WIDE(GV_STORE16, 1, grid); break;
             case GV_RESID: PGV_GEMV_WIDE(GV_RESID, 1, grid); break;
-            case GV_SWIGLU: if (grid % 2 == 0 && B <= 32) PGV_GEMV_W(GV_SWIGLU, 4, 2, grid / 2); else PGV_GEMV_WIDE(GV_SWIGLU, 2, grid); break;
+            case GV_SWIGLU: if (grid % 2 == 0 && B <= 32) PGV_GEMV_W(GV_SWIGLU, 4, 2, grid / 2); else PGV_GEMV_WIDE(GV_SWIGLU, 2, grid); break;   // (4 row blocks x 4 column tiles spill)
             case GV_F32: PGV_GEMV_WIDE(GV_F32, 1, grid); break;
             case GV_RESIDNORM: PGV_GEMV_WIDE(GV_RESIDNORM, 1, grid); break;
             default: pgv_set_error("gemv: bad mode %d", mode); return PGV_EINVAL;
