@@ -16,7 +16,8 @@ int pgv_launch_rope_kv_write(int dtype, void* qkv, const int* row_b, const int* 
 int pgv_launch_prefill_attn(pgv_ctx* ctx, int dtype, const void* qkv, void* out, const void* Kc, const void* Vc, const int* cu, int B, int max_len,
                             int H, int heads, int max_seq, double flops, hipStream_t s);
 int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void* x, int ldx, void* out, int ldo, int N, int K, int B, hipStream_t s,
-                    const float* wscale = nullptr, const GemvNorm* norm = nullptr);
+                    const float* wscale = nullptr, const GemvNorm* norm = nullptr, const float* xscale = nullptr);
+int pgv_launch_quant_hilo(int dtype, const void* x, int ldx, int K, int B, void* x8, float* scales, hipStream_t s);
 int pgv_launch_embed_tok_norm(int dtype, const int* tok, const void* embed, float* resid, const float* gamma, void* xg, float* ssq, int B, int H, hipStream_t s);
 int pgv_launch_quantize_fp8(int dtype, void* w16_blocked, void* w8_blocked, float* scales, long long N, long long K, hipStream_t s);
 int pgv_launch_unpack_blocked(int dtype, const void* src, float* dst, long long N, long long K, long long row_blk, long long blk_stride, long long row_off,
@@ -73,6 +74,7 @@ struct pgv_kv {
     float* amax_val; int* amax_idx;     // greedy candidates of the lm_head GEMV, tile-major: [ceil(B / 16)][vocab_cap / 16][16]
     float* ssq;                         // sum-of-squares partials of the folded RMSNorm, tile-major: [ceil(B / 16)][hidden / 16][16] (see GemvArgs in llm_kernels.hip)
     int ssq_ts, amax_ts;                // their tile strides in elements: hidden, vocab_cap
+    void* x8; float* xscale;            // fp8 x fp8 MFMA form (PGV_FP8_MFMA=1): hi / lo e4m3 image of the current GEMV's activation operand [B][max(hidden, inter)] x 2 B, scales [B][2]
     float* dattn_part; unsigned* dattn_ticket;   // context-split decode attention: partial states [B * heads][8][130], arrival tickets [B * heads] (zero between launches)
     int *d_pos, *d_cur, *d_step, *d_done, *d_hist;
     std::vector<int> h_len;
@@ -303,7 +305,8 @@ extern "C" int pgv_kv_create(pgv_ctx* ctx, pgv_llm* llm, int batch, int max_seq,
     const size_t o_cache = take(per * 2 * L);
     const size_t o_resid = take(B * H * 4), o_xn = take(B * H * 2), o_qkv = take(B * 3 * H * 2), o_ao = take(B * H * 2), o_act = take(B * I * 2),
                  o_logits = take(B * V * 4), o_ssq = take(CTn * H * 4), o_av = take(CTn * V * 4), o_ai = take(CTn * V * 4), o_ints = take((4 * B + B * (size_t)max_seq) * 4),
-                 o_u = take(B * (size_t)max_seq * 4), o_dpart = take(B * llm->cfg.heads * (size_t)kDattnSplitMax * kDattnPart * 4), o_dtick = take(B * llm->cfg.heads * 4);
+                 o_u = take(B * (size_t)max_seq * 4), o_dpart = take(B * llm->cfg.heads * (size_t)kDattnSplitMax * kDattnPart * 4), o_dtick = take(B * llm->cfg.heads * 4),
+                 o_x8 = take(B * (I > H ? I : H) * 2), o_xs = take(B * 2 * 4);
     hipError_t e = hipMalloc((void**)&kv->blob, off);
     if (e != hipSuccess) { delete kv; pgv_set_error("pgv_kv_create: hipMalloc(%zu MiB): %s", off >> 20, hipGetErrorString(e)); return PGV_ENOMEM; }
     char* b = kv->blob;
@@ -313,6 +316,7 @@ extern "C" int pgv_kv_create(pgv_ctx* ctx, pgv_llm* llm, int batch, int max_seq,
     kv->d_pos = ints; kv->d_cur = ints + B; kv->d_step = ints + 2 * B; kv->d_done = ints + 3 * B; kv->d_hist = ints + 4 * B;
     kv->d_u = (float*)(b + o_u);
     kv->dattn_part = (float*)(b + o_dpart); kv->dattn_ticket = (unsigned*)(b + o_dtick);
+    kv->x8 = b + o_x8; kv->xscale = (float*)(b + o_xs);
     e = hipMemset(ints, 0, (4 * B + B * (size_t)max_seq) * 4);
     if (e == hipSuccess) e = hipMemset(kv->dattn_ticket, 0, B * llm->cfg.heads * 4);
     if (e == hipSuccess) e = hipMemset(kv->ssq, 0, CTn * H * 4);
@@ -346,13 +350,35 @@ static bool norm_fold_enabled() {
     return v == 1;
 }
 
+// PGV_FP8_MFMA=1 (with fp8 weights, folded norms, at most 16 sequences): the decode GEMVs run as v_mfma_f32_16x16x32_fp8_fp8 on the e4m3 weight
+// codes and a hi + lo e4m3 image of the activation (llm_kernels.hip, A8).  A measured alternative, not the default: the image costs one small
+// launch per GEMV and moves the same bytes as the 16-bit operand, so it buys no bandwidth (LAB.md).
+static bool fp8_mfma_enabled() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("PGV_FP8_MFMA"); v = (e && e[0] == '1') ? 1 : 0; }
+    return v == 1;
+}
+
+// One decode GEMV on the fp8 weights: weight-only form (16-bit x, codes widened in registers) or, under the flag, the fp8 x fp8 form.
+static int gemv8(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int mode, const void* w8, const float* ws, const void* x, int K, void* out, int ldo, int N, int B,
+                 hipStream_t s, const GemvNorm* nm) {
+    if (fp8_mfma_enabled() && B <= 16) {
+        pgv_prof_begin(ctx, 6, s);
+        PGV_TRY(pgv_launch_quant_hilo(m->dtype, x, K, K, B, kv->x8, kv->xscale, s));
+        pgv_prof_end(ctx, 6, s, 0.0, 0.0);
+        return pgv_launch_gemv(ctx, m->dtype, mode, w8, kv->x8, K, out, ldo, N, K, B, s, ws, nm, kv->xscale);
+    }
+    return pgv_launch_gemv(ctx, m->dtype, mode, w8, x, K, out, ldo, N, K, B, s, ws, nm);
+}
+
 static int lm_head_and_pick(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int B, int eos, int flags, hipStream_t s, int nparts) {
     const int H = m->cfg.hidden, V = m->cfg.vocab;
     GemvNorm nm; nm.ssq_in = nparts > 0 ? kv->ssq : nullptr; nm.nparts_in = nparts; nm.hidden = H; nm.eps = m->cfg.eps;     // nparts 0: kv->xn is already normalised
     nm.ssq_ts = kv->ssq_ts; nm.amax_ts = kv->amax_ts;
     const bool greedy = !(flags & AM_SAMPLE);
     if (greedy) { nm.amax_val = kv->amax_val; nm.amax_idx = kv->amax_idx; }
-    PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_F32, m->fp8 ? m->q_head : m->lm_head, kv->xn, H, kv->logits, V, V, H, B, s, m->fp8 ? m->s_head : nullptr, &nm));
+    if (m->fp8 && nparts > 0) PGV_TRY(gemv8(ctx, m, kv, GV_F32, m->q_head, m->s_head, kv->xn, H, kv->logits, V, V, B, s, &nm));
+    else PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_F32, m->fp8 ? m->q_head : m->lm_head, kv->xn, H, kv->logits, V, V, H, B, s, m->fp8 ? m->s_head : nullptr, &nm));
     pgv_prof_begin(ctx, 6, s);
     if (flags & AM_SAMPLE)
         PGV_TRY(pgv_launch_sample(kv->logits, V, B, kv->s_temp, kv->s_topk, kv->d_u, B, 1, kv->d_cur, kv->d_pos, kv->d_step, kv->d_hist, kv->max_seq, kv->d_done,
@@ -496,14 +522,18 @@ static int decode_enqueue(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int eos, int fla
         const LlmLayer& l = m->layers[li];
         const bool q8 = m->fp8;
         GemvNorm cons; cons.ssq_in = kv->ssq; cons.nparts_in = parts_in; cons.hidden = H; cons.eps = m->cfg.eps; cons.ssq_ts = kv->ssq_ts;
-        PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_STORE16, q8 ? l.q_wqkv : l.wqkv, kv->xn, H, kv->qkv, 3 * H, 3 * H, H, B, s, q8 ? l.s_wqkv : nullptr, &cons));
+        if (q8) PGV_TRY(gemv8(ctx, m, kv, GV_STORE16, l.q_wqkv, l.s_wqkv, kv->xn, H, kv->qkv, 3 * H, 3 * H, B, s, &cons));
+        else PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_STORE16, l.wqkv, kv->xn, H, kv->qkv, 3 * H, 3 * H, H, B, s, nullptr, &cons));
         PGV_TRY(pgv_launch_decode_attn(ctx, m->dtype, kv->qkv, kv->d_pos, m->rope, kv->Kc[li], kv->Vc[li], kv->ao, B, H, heads, kv->max_seq, kv_bytes, s, kv->dattn_part, kv->dattn_ticket));
         GemvNorm prod; prod.gamma = l.post_g; prod.xg = kv->xn; prod.ssq_out = kv->ssq; prod.ssq_ts = kv->ssq_ts;
-        PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_RESIDNORM, q8 ? l.q_wo : l.wo, kv->ao, H, kv->resid, H, H, H, B, s, q8 ? l.s_wo : nullptr, &prod));
+        if (q8) PGV_TRY(gemv8(ctx, m, kv, GV_RESIDNORM, l.q_wo, l.s_wo, kv->ao, H, kv->resid, H, H, B, s, &prod));
+        else PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_RESIDNORM, l.wo, kv->ao, H, kv->resid, H, H, H, B, s, nullptr, &prod));
         cons.nparts_in = nparts;
-        PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_SWIGLU, q8 ? l.q_wgu : l.wgu, kv->xn, H, kv->act, I, 2 * I, H, B, s, q8 ? l.s_wgu : nullptr, &cons));
+        if (q8) PGV_TRY(gemv8(ctx, m, kv, GV_SWIGLU, l.q_wgu, l.s_wgu, kv->xn, H, kv->act, I, 2 * I, B, s, &cons));
+        else PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_SWIGLU, l.wgu, kv->xn, H, kv->act, I, 2 * I, H, B, s, nullptr, &cons));
         prod.gamma = li + 1 < L ? m->layers[li + 1].in_g : m->norm_g;
-        PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_RESIDNORM, q8 ? l.q_wdown : l.wdown, kv->act, I, kv->resid, H, H, I, B, s, q8 ? l.s_wdown : nullptr, &prod));
+        if (q8) PGV_TRY(gemv8(ctx, m, kv, GV_RESIDNORM, l.q_wdown, l.s_wdown, kv->act, I, kv->resid, H, H, B, s, &prod));
+        else PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_RESIDNORM, l.wdown, kv->act, I, kv->resid, H, H, I, B, s, nullptr, &prod));
         parts_in = nparts;
     }
     PGV_TRY(lm_head_and_pick(ctx, m, kv, B, eos, flags, s, parts_in));

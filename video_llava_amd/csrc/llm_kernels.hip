@@ -289,6 +289,8 @@ struct GemvArgs {
     // batches beyond one MFMA tile (CT column tiles of 16 sequences, B <= 16 CT): every per-batch-column side array above is tile-major,
     // [CT][...][16], with these tile strides in elements
     int ssq_ts, amax_ts;
+    // A8 (the fp8 x fp8 MFMA form, PGV_FP8_MFMA=1): x is the hi / lo e4m3 image written by quant_hilo_kernel, xscale [B][2] its per-token scales
+    const float* xscale;
 };
 
 // W8 = true streams the fp8 (e4m3) blocked copy of the matrix: one 16-byte load per lane carries the A fragments of TWO consecutive
@@ -331,11 +333,19 @@ __device__ __forceinline__ typename T::v8 fp8x8_to_v8(unsigned lo, unsigned hi) 
 // CT (round 4): column tiles of 16 sequences per weight fragment, B <= 16 CT (decode batches up to 64).  The weights are still streamed once;
 // every tile is a separate pass of the 16-column arithmetic (its own accumulators, its own sum-of-squares reduction, its own epilogue), so a
 // sequence's results are BITWISE the same whether it is decoded alone or next to 63 others.
-template <typename T, int MODE, bool W8, int NW, int TL, int PU, bool X2, int CT = 1>
+// A8 (round 4; BASELINE configs[4] names an "fp8 MFMA weight path"): the weights' e4m3 codes go into v_mfma_f32_16x16x32_fp8_fp8 as they are
+// (no widening VALU) and the activation enters as TWO e4m3 operands, x ~ s_hi hi + s_lo lo (quant_hilo_kernel below: per-token power-of-two
+// scales from the exact amax of x and of x - s_hi hi), one MFMA each into separate accumulators that the epilogue combines.  Products of
+// e4m3 pairs are exact in fp32, so the only error against the weight-only path is the 7 - 8 bits the pair keeps of every activation:
+// oracle/a8_study.py measures 1.8e-2 on the 40-layer 13B logits (plain e4m3 activations: 5.9e-1; bf16 activations: 6.7e-2).  The x image
+// has the 16-bit operand's footprint (16 B per 8 values: 8 hi codes, 8 lo codes), so every load above is unchanged.
+template <typename T, int MODE, bool W8, int NW, int TL, int PU, bool X2, int CT = 1, bool A8 = false>
 __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
     constexpr int TILES = TL;
     static_assert(!X2 || CT == 1, "the merged x load uses the lanes of columns 8..15");
+    static_assert(!A8 || (W8 && CT == 1), "the fp8 x fp8 form streams the fp8 weights; batches up to 16");
     __shared__ f32x4_t red[NW][TILES * CT][64];
+    __shared__ f32x4_t red2[A8 ? NW : 1][A8 ? TILES : 1][64];
     __shared__ f32x4_t ssq_red[NW][4 * CT];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -388,10 +398,13 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
         return __builtin_bit_cast(typename T::v8, __builtin_amdgcn_raw_buffer_load_b128(xrs, xvo[ct] + (unsigned)(kb * 64), 0, 0));
     };
     f32x4_t acc[TILES][CT];
+    f32x4_t acc2[A8 ? TILES : 1];                                // A8: the lo operand's accumulators
 #pragma unroll
     for (int t = 0; t < TILES; ++t)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) acc[t][ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < (A8 ? TILES : 1); ++t) acc2[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     {
         // groups (64 columns) j_lo + w + NW * g, g = 0 .. : batch b holds g = b * PU .. b * PU + PU - 1.  Every batch but the last is complete
         // for every wave (the waves' group counts differ by at most one); in the last batch, entries past the end re-read the last valid
@@ -456,11 +469,18 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
                 for (int t = 0; t < TILES; ++t)
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        typename T::v8 wv;
-                        if constexpr (W8) wv = fp8x8_to_v8<T>(wf[u][0][t][2 * h], wf[u][0][t][2 * h + 1]);      // widened once, used by every column tile
-                        else wv = wf[u][h][t];
+                        if constexpr (A8) {
+                            const long wq = (long)(((unsigned long)wf[u][0][t][2 * h + 1] << 32) | (unsigned long)wf[u][0][t][2 * h]);
+                            const u32x4_t xr = __builtin_bit_cast(u32x4_t, xv[h][0]);
+                            acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wq, (long)(((unsigned long)xr[1] << 32) | (unsigned long)xr[0]), acc[t][0], 0, 0, 0);
+                            acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wq, (long)(((unsigned long)xr[3] << 32) | (unsigned long)xr[2]), acc2[t], 0, 0, 0);
+                        } else {
+                            typename T::v8 wv;
+                            if constexpr (W8) wv = fp8x8_to_v8<T>(wf[u][0][t][2 * h], wf[u][0][t][2 * h + 1]);      // widened once, used by every column tile
+                            else wv = wf[u][h][t];
 #pragma unroll
-                        for (int ct = 0; ct < CT; ++ct) acc[t][ct] = T::mfma16(wv, xv[h][ct], acc[t][ct]);
+                            for (int ct = 0; ct < CT; ++ct) acc[t][ct] = T::mfma16(wv, xv[h][ct], acc[t][ct]);
+                        }
                     }
             }
         };
@@ -491,6 +511,10 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
     for (int t = 0; t < TILES; ++t)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) red[w][t * CT + ct][lane] = acc[t][ct];
+    if constexpr (A8) {
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) red2[w][t][lane] = acc2[t];
+    }
     if (scaled) {
       const int n4 = p.nparts_in * 4;
 #pragma unroll
@@ -522,6 +546,13 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
         tot[t] = red[0][t * CT + ct][lane];
 #pragma unroll
         for (int ww = 1; ww < NW; ++ww) tot[t] += red[ww][t * CT + ct][lane];
+        if constexpr (A8) {                                       // y = s_hi (W hi) + s_lo (W lo), per batch column
+            f32x4_t lo = red2[0][t][lane];
+#pragma unroll
+            for (int ww = 1; ww < NW; ++ww) lo += red2[ww][t][lane];
+            const float sh = l15 < p.B ? p.xscale[l15 * 2] : 0.f, sl = l15 < p.B ? p.xscale[l15 * 2 + 1] : 0.f;
+            tot[t] = tot[t] * sh + lo * sl;
+        }
     }
     if constexpr (W8) {                                           // per-row power-of-two scale: exact in fp32
 #pragma unroll
@@ -591,6 +622,69 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
             if (n0 + r < p.N) op[r] = tot[0][r];
     }
     }   // column tiles
+}
+
+// Activation image of the fp8 x fp8 form: x [B][K] 16-bit -> x8 [B][K / 8][16 B] (8 hi codes, 8 lo codes per 8 consecutive k: the 16-bit
+// operand's footprint, so the GEMV's x loads are unchanged) + scales [B][2] = (s_hi, s_lo), each 2^ceil(log2(amax / 448)) of what it scales
+// (the rule of the weight quantiser, fp8.hip): hi = e4m3(x / s_hi), lo = e4m3((x - s_hi hi) / s_lo), round to nearest even.  One workgroup
+// per sequence; x is read three times from L2 (amax, residual amax, codes).
+__device__ __forceinline__ float pow2_scale_448(float m) {
+    if (!(m > 0.f)) return 1.0f;
+    int e;
+    const float fr = frexpf(m / 448.0f, &e);
+    return ldexpf(1.0f, fr == 0.5f ? e - 1 : e);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void quant_hilo_kernel(const typename T::elem* __restrict__ x, int ldx, int K, unsigned char* __restrict__ x8, float* __restrict__ scales) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const typename T::elem* xr = x + (size_t)b * ldx;
+    auto block_max = [&](float v) -> float {
+        v = wave_max(v);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = v;
+        __syncthreads();
+        return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    };
+    float am = 0.f;
+    for (int c = tid * 8; c < K; c += 2048) {
+        const typename T::v8 v = *(const typename T::v8*)(xr + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) am = fmaxf(am, fabsf((float)v[e]));
+    }
+    const float s_hi = pow2_scale_448(block_max(am)), inv_hi = 1.0f / s_hi;
+    auto hi_codes = [&](const typename T::v8& v, unsigned (&code)[2], float (&resid)[8]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float a = (float)v[2 * q], c2 = (float)v[2 * q + 1];
+            const int pk = __builtin_amdgcn_cvt_pk_fp8_f32(a * inv_hi, c2 * inv_hi, 0, false);
+            const f32x2_t back = __builtin_amdgcn_cvt_pk_f32_fp8(pk, false);
+            resid[2 * q] = a - back[0] * s_hi; resid[2 * q + 1] = c2 - back[1] * s_hi;     // exact: both terms on the grid of a's last bit or coarser
+            if (q & 1) code[q >> 1] |= (unsigned)(pk & 0xffff) << 16; else code[q >> 1] = (unsigned)(pk & 0xffff);
+        }
+    };
+    float am2 = 0.f;
+    for (int c = tid * 8; c < K; c += 2048) {
+        const typename T::v8 v = *(const typename T::v8*)(xr + c);
+        unsigned code[2]; float r[8];
+        hi_codes(v, code, r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) am2 = fmaxf(am2, fabsf(r[e]));
+    }
+    const float s_lo = pow2_scale_448(block_max(am2)), inv_lo = 1.0f / s_lo;
+    for (int c = tid * 8; c < K; c += 2048) {
+        const typename T::v8 v = *(const typename T::v8*)(xr + c);
+        unsigned hi[2], lo[2]; float r[8];
+        hi_codes(v, hi, r);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int pk = __builtin_amdgcn_cvt_pk_fp8_f32(r[2 * q] * inv_lo, r[2 * q + 1] * inv_lo, 0, false);
+            if (q & 1) lo[q >> 1] |= (unsigned)(pk & 0xffff) << 16; else lo[q >> 1] = (unsigned)(pk & 0xffff);
+        }
+        *(u32x4_t*)(x8 + ((size_t)b * K + c) * 2) = u32x4_t{hi[0], hi[1], lo[0], lo[1]};
+    }
+    if (tid == 0) { scales[b * 2] = s_hi; scales[b * 2 + 1] = s_lo; }
 }
 
 // decode: resid[b] = embed[tok[b]] plus the producer side of the folded RMSNorm (see GemvArgs): xg = round16(resid * gamma of layer 0's
@@ -1215,15 +1309,22 @@ int pgv_launch_embed_tok_norm(int dtype, const int* tok, const void* embed, floa
     return PGV_OK;
 }
 
+int pgv_launch_quant_hilo(int dtype, const void* x, int ldx, int K, int B, void* x8, float* scales, hipStream_t s) {
+    PGV_CHECK(K % 8 == 0 && B >= 1, "quant_hilo: K=%d must be a multiple of 8", K);
+    PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((quant_hilo_kernel<T>), dim3(B), dim3(256), 0, s, (const typename T::elem*)x, ldx, K, (unsigned char*)x8, scales));
+    return PGV_OK;
+}
+
 int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void* x, int ldx, void* out, int ldo, int N, int K, int B, hipStream_t s,
-                    const float* wscale, const GemvNorm* norm) {
+                    const float* wscale, const GemvNorm* norm, const float* xscale) {
     PGV_CHECK(B >= 1 && B <= 64, "gemv: batch %d outside [1,64]", B);
     PGV_CHECK(K % 32 == 0, "gemv: K=%d must be a multiple of 32", K);
     const bool w8 = wscale != nullptr;                  // W is the fp8 blocked copy (fp8.hip) with per-row scales
     GemvArgs a;
     a.W = (const char*)W; a.x = (const char*)x; a.out = (char*)out; a.N = N; a.K = K; a.B = B; a.ldx = ldx; a.ldo = ldo; a.wscale = wscale;
     a.ssq_in = nullptr; a.nparts_in = 0; a.inv_h = 0.f; a.eps = 0.f; a.gamma = nullptr; a.xg = nullptr; a.ssq_out = nullptr; a.amax_val = nullptr; a.amax_idx = nullptr;
-    a.ssq_ts = 0; a.amax_ts = 0;
+    a.ssq_ts = 0; a.amax_ts = 0; a.xscale = xscale;
+    PGV_CHECK(xscale == nullptr || (w8 && B <= 16 && mode != GV_RESID), "gemv: the fp8 x fp8 form needs fp8 weights, at most 16 sequences and a folded-norm mode");
     PGV_CHECK(B <= 16 || norm == nullptr || (norm->ssq_ts > 0 && (norm->amax_val == nullptr || norm->amax_ts > 0)), "gemv: batches beyond 16 need the tile strides of the side arrays");
     if (norm) {
         a.ssq_ts = norm->ssq_ts; a.amax_ts = norm->amax_ts;
@@ -1262,6 +1363,21 @@ int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void
             default: pgv_set_error("gemv: bad mode %d", mode); return PGV_EINVAL;
         }
         pgv_prof_end(ctx, 3, s, 2.0 * B * (double)N * K, (w8 ? 1.0 : 2.0) * (double)N * K);
+        return PGV_OK;
+    }
+    if (xscale) {                                       // fp8 x fp8 MFMA form (flag path)
+#define PGV_GEMV_A8(MODE_, TL_, PU_, GRID_) do { \
+        if (B <= 8) PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gemv_mfma_kernel<T, MODE_, true, 8, TL_, PU_, true, 1, true>), dim3(GRID_), dim3(512), 0, s, a)); \
+        else PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gemv_mfma_kernel<T, MODE_, true, 8, TL_, PU_, false, 1, true>), dim3(GRID_), dim3(512), 0, s, a)); } while (0)
+        switch (mode) {
+            case GV_STORE16: if (grid % 3 == 0 && grid / 3 <= 2 * ctx->num_cu) PGV_GEMV_A8(GV_STORE16, 3, 2, grid / 3); else PGV_GEMV_A8(GV_STORE16, 1, 4, grid); break;
+            case GV_SWIGLU: PGV_GEMV_A8(GV_SWIGLU, 2, 2, grid); break;
+            case GV_F32: PGV_GEMV_A8(GV_F32, 1, 4, grid); break;
+            case GV_RESIDNORM: PGV_GEMV_A8(GV_RESIDNORM, 1, 4, grid); break;
+            default: pgv_set_error("gemv: mode %d has no fp8 x fp8 form", mode); return PGV_EINVAL;
+        }
+#undef PGV_GEMV_A8
+        pgv_prof_end(ctx, 3, s, 2.0 * B * (double)N * K, (double)N * K);
         return PGV_OK;
     }
     static int tl3 = -1, x2env = -1;
@@ -1362,7 +1478,7 @@ extern "C" int pgv_gemv(pgv_ctx* ctx, int dtype, int mode, const void* d_W, cons
                         void* stream) {
     PGV_CHECK(ctx && d_W && d_x && d_out, "pgv_gemv: null argument");
     PGV_CHECK(mode >= 0 && mode <= 3, "pgv_gemv: mode %d outside [0,3]", mode);
-    return pgv_launch_gemv(ctx, dtype, mode, d_W, d_x, ldx, d_out, ldo, N, K, B, (hipStream_t)stream, nullptr, nullptr);
+    return pgv_launch_gemv(ctx, dtype, mode, d_W, d_x, ldx, d_out, ldo, N, K, B, (hipStream_t)stream, nullptr, nullptr, nullptr);
 }
 
 #include "weights.h"
@@ -1377,5 +1493,19 @@ extern "C" int pgv_gemv_fp8(pgv_ctx* ctx, int dtype, int mode, const void* d_W8,
                             int K, int B, void* stream) {
     PGV_CHECK(ctx && d_W8 && d_scales && d_x && d_out, "pgv_gemv_fp8: null argument");
     PGV_CHECK(mode >= GV_STORE16 && mode <= GV_F32, "pgv_gemv_fp8: mode %d outside [0,3]", mode);
-    return pgv_launch_gemv(ctx, dtype, mode, d_W8, d_x, ldx, d_out, ldo, N, K, B, (hipStream_t)stream, d_scales, nullptr);
+    return pgv_launch_gemv(ctx, dtype, mode, d_W8, d_x, ldx, d_out, ldo, N, K, B, (hipStream_t)stream, d_scales, nullptr, nullptr);
+}
+
+extern "C" int pgv_quantize_act_hilo(pgv_ctx* ctx, int dtype, const void* d_x, int ldx, int B, int K, void* d_x8, float* d_xscales, void* stream) {
+    PGV_CHECK(ctx && d_x && d_x8 && d_xscales && B >= 1 && B <= 64, "pgv_quantize_act_hilo: bad arguments");
+    PGV_TRY(pgv_launch_quant_hilo(dtype, d_x, ldx, K, B, d_x8, d_xscales, (hipStream_t)stream));
+    PGV_HIP(hipGetLastError());
+    return PGV_OK;
+}
+
+extern "C" int pgv_gemv_fp8_a8(pgv_ctx* ctx, int dtype, int mode, const void* d_W8, const float* d_wscales, const void* d_x8, const float* d_xscales, void* d_out,
+                               int ldo, int N, int K, int B, void* stream) {
+    PGV_CHECK(ctx && d_W8 && d_wscales && d_x8 && d_xscales && d_out, "pgv_gemv_fp8_a8: null argument");
+    PGV_CHECK(mode == GV_STORE16 || mode == GV_SWIGLU || mode == GV_F32, "pgv_gemv_fp8_a8: mode %d outside {0, 2, 3}", mode);
+    return pgv_launch_gemv(ctx, dtype, mode, d_W8, d_x8, K, d_out, ldo, N, K, B, (hipStream_t)stream, d_wscales, nullptr, d_xscales);
 }
