@@ -185,6 +185,10 @@ __device__ __forceinline__ void epilogue_w4(const KArgs& p, f32x16_t (&acc)[4][4
             bv[jp] = *(const f32x4_t*)(p.bias + min(col, p.N - 4));
         }
     }
+#ifndef PGV_LAB_EPI_AUX
+#define PGV_LAB_EPI_AUX 2               // cache-policy bits of the fp32-residual read-modify-write: 2 = non-temporal.  The residual (842 MB per 400-frame
+#endif                                  // lane) is touched once per producer GEMM and is far larger than L2 + Infinity Cache: streaming it past the L2 keeps the
+                                        // A / W panels of the K loop resident.  A/B on one box (gpurun_out/r4l): vision bench 121.92 / 122.06 -> 121.28 / 121.45 ms
     u32x2_t rst[8];                                            // LN_IN: (mean - centre, rstd) of the 8 rows
     float cm[8];                                               // LN_OUT: centre of the 8 rows
     float csh = 0.f;
@@ -208,7 +212,7 @@ __device__ __forceinline__ void epilogue_w4(const KArgs& p, f32x16_t (&acc)[4][4
         u32x4_t old[8];
         if constexpr (RMW) {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) old[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[jp] + (i * 32 + r * 4) * rowpitch, 0, 0);
+            for (int r = 0; r < 8; ++r) old[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[jp] + (i * 32 + r * 4) * rowpitch, 0, PGV_LAB_EPI_AUX);
         }
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
@@ -250,7 +254,7 @@ __device__ __forceinline__ void epilogue_w4(const KArgs& p, f32x16_t (&acc)[4][4
                     const f32x4_t q = __builtin_bit_cast(f32x4_t, old[r]);
                     d[0] += q[0]; d[1] += q[1]; d[2] += q[2]; d[3] += q[3];
                 }
-                if constexpr (OUT32) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, d), rsrc, o, 0, 0);
+                if constexpr (OUT32) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, d), rsrc, o, 0, RMW ? PGV_LAB_EPI_AUX : 0);
                 else __builtin_amdgcn_raw_buffer_store_b64(pack4<T>(d[0], d[1], d[2], d[3]), rsrc, o, 0, 0);
                 if constexpr (LN_OUT) {
                     d[0] -= cm[r]; d[1] -= cm[r]; d[2] -= cm[r]; d[3] -= cm[r];           // centred from here on (the fp32 residual above is not)
@@ -481,7 +485,7 @@ int launch_w4(const KArgs& k, hipStream_t s, int num_cu) {
     // Lab builds only (-DPGV_LAB): timing ablations (results are garbage), plain BIAS epilogue in bf16 only -- PGV_GEMM_ABLATE bits: 1 no DMA,
     // 2 no fragment reads, 4 no MFMA, 8 no counted vmcnt wait, 16 no barrier, 32 no epilogue (scripts/microbench.py ablate,
     // scripts/lab/gemm_epi_decomp.py).
-    // The release library has no switch that changes results.
+    // The release library has no garbage-producing ablation switch (its documented A/B switches, INTEGRATION.md, all pass the parity tests).
     if constexpr (EPI == PGV_EPI_BIAS && T::id == PGV_BF16) {
         switch (abl) {
             case 1: return launch_w4_inst<T, EPI, 1>(k, s, num_cu);

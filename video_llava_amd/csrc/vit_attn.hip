@@ -41,7 +41,7 @@ struct AttnArgs {
 #ifdef PGV_LAB
 #define PGV_ATTN_ABL(p) ((p).abl)
 #else
-#define PGV_ATTN_ABL(p) 0          // the release library has no switch that changes results
+#define PGV_ATTN_ABL(p) 0          // the release library has no garbage-producing ablation switch (documented A/B switches: INTEGRATION.md)
 #endif
 
 template <typename T, int ABL>
