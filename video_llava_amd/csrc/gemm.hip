@@ -185,6 +185,10 @@ __device__ __forceinline__ void epilogue_w4(const KArgs& p, f32x16_t (&acc)[4][4
             bv[jp] = *(const f32x4_t*)(p.bias + min(col, p.N - 4));
         }
     }
+#ifndef PGV_LAB_OUT16_AUX
+#define PGV_LAB_OUT16_AUX 2             // cache-policy bits of the 16-bit output stores of the LayerNorm-consumer GEMMs (qkv, fc1): non-temporal -- outputs of
+#endif                                  // 0.6 - 0.8 GB per lane that the next kernel streams once; A/B (gpurun_out/r4m): 125.26 / 125.52 -> 124.89 / 125.28 ms.
+                                        // (The A-operand DMA with the same hint: 132.2 / 133.4 ms -- the panels ARE re-read by the other tile columns.)
 #ifndef PGV_LAB_EPI_AUX
 #define PGV_LAB_EPI_AUX 2               // cache-policy bits of the fp32-residual read-modify-write: 2 = non-temporal.  The residual (842 MB per 400-frame
 #endif                                  // lane) is touched once per producer GEMM and is far larger than L2 + Infinity Cache: streaming it past the L2 keeps the
@@ -255,7 +259,7 @@ __device__ __forceinline__ void epilogue_w4(const KArgs& p, f32x16_t (&acc)[4][4
                     d[0] += q[0]; d[1] += q[1]; d[2] += q[2]; d[3] += q[3];
                 }
                 if constexpr (OUT32) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, d), rsrc, o, 0, RMW ? PGV_LAB_EPI_AUX : 0);
-                else __builtin_amdgcn_raw_buffer_store_b64(pack4<T>(d[0], d[1], d[2], d[3]), rsrc, o, 0, 0);
+                else __builtin_amdgcn_raw_buffer_store_b64(pack4<T>(d[0], d[1], d[2], d[3]), rsrc, o, 0, LN_IN ? PGV_LAB_OUT16_AUX : 0);
                 if constexpr (LN_OUT) {
                     d[0] -= cm[r]; d[1] -= cm[r]; d[2] -= cm[r]; d[3] -= cm[r];           // centred from here on (the fp32 residual above is not)
                     __builtin_amdgcn_raw_buffer_store_b64(pack4<T>(d[0] * sv[jp][0], d[1] * sv[jp][1], d[2] * sv[jp][2], d[3] * sv[jp][3]), rs_aux,
@@ -338,8 +342,11 @@ __global__ __launch_bounds__(256, 1) void gemm_w4(KArgs p) {
 #ifndef PGV_LAB_DMA_AUX
 #define PGV_LAB_DMA_AUX 0               // cache-policy bits of the operand DMA (lab A/B: 1 = sc0, 2 = sc1, 8 = nt ...)
 #endif
+#ifndef PGV_LAB_DMA_A_AUX
+#define PGV_LAB_DMA_A_AUX PGV_LAB_DMA_AUX   // ... of the A operand alone
+#endif
             __builtin_amdgcn_raw_ptr_buffer_load_lds(which == 0 ? rsA : rsW, (__attribute__((address_space(3))) void*)dst, 16,
-                                                     which == 0 ? voffA[j] : voffW[j], which == 0 ? a_k : w_k, 0, PGV_LAB_DMA_AUX);
+                                                     which == 0 ? voffA[j] : voffW[j], which == 0 ? a_k : w_k, 0, which == 0 ? PGV_LAB_DMA_A_AUX : PGV_LAB_DMA_AUX);
         }
     };
     auto advance = [&](auto which_c) __attribute__((always_inline)) {             // cursor -> the same tile kind of the next K-step
