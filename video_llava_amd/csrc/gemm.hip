@@ -342,11 +342,15 @@ __global__ __launch_bounds__(256, 1) void gemm_w4(KArgs p) {
 #ifndef PGV_LAB_DMA_AUX
 #define PGV_LAB_DMA_AUX 0               // cache-policy bits of the operand DMA (lab A/B: 1 = sc0, 2 = sc1, 8 = nt ...)
 #endif
+#ifndef PGV_LAB_DMA_A_LNIN_AUX
+#define PGV_LAB_DMA_A_LNIN_AUX 0            // ... of the A operand of the LayerNorm-consumer GEMMs (qkv, fc1: W-resident order, every A panel read once per XCD)
+#endif
 #ifndef PGV_LAB_DMA_A_AUX
 #define PGV_LAB_DMA_A_AUX PGV_LAB_DMA_AUX   // ... of the A operand alone
 #endif
             __builtin_amdgcn_raw_ptr_buffer_load_lds(which == 0 ? rsA : rsW, (__attribute__((address_space(3))) void*)dst, 16,
-                                                     which == 0 ? voffA[j] : voffW[j], which == 0 ? a_k : w_k, 0, which == 0 ? PGV_LAB_DMA_A_AUX : PGV_LAB_DMA_AUX);
+                                                     which == 0 ? voffA[j] : voffW[j], which == 0 ? a_k : w_k, 0,
+                                                     which == 0 ? ((EPI == EPI_LN_BIAS || EPI == EPI_LN_BIAS_QGELU) ? PGV_LAB_DMA_A_LNIN_AUX : PGV_LAB_DMA_A_AUX) : PGV_LAB_DMA_AUX);
         }
     };
     auto advance = [&](auto which_c) __attribute__((always_inline)) {             // cursor -> the same tile kind of the next K-step
