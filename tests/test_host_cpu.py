@@ -286,6 +286,21 @@ def test_release_library_has_no_lab_switches():
     assert "use_lab_build" not in src and "libpgv_lab" not in src
 
 
+def test_sanitizer_build_of_the_host_shim_builds_and_loads():
+    """libpgv_ubsan.so -- UBSan (non-recoverable) + libstdc++ container assertions on the host code of every translation unit,
+    release kernels -- must build for gfx950 and export the whole C ABI under its preloaded runtime (the GPU suite runs under it with
+    scripts/sessions/r4_ubsan.sh: 198 passed, 0 reports, profiles/r04_a_ubsan_gpu_tests.txt).  Nothing in the product binds it."""
+    from video_llava_amd import _lib, build
+    lib = build.build_sanitizer()
+    rt = build.sanitizer_runtime()
+    code = ("import ctypes, sys; sys.path.insert(0, %r); from video_llava_amd import _lib; _lib.LIB_PATH = %r; l = _lib.load(build_if_missing=False); "
+            "print('OK', l.pgv_version(), len(_lib.PROTOTYPES))" % (ROOT, lib))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, LD_PRELOAD=rt))
+    assert r.returncode == 0 and r.stdout.startswith(f"OK {_lib.ABI_VERSION} "), (r.stdout, r.stderr[-2000:])
+    src = "".join(open(os.path.join(ROOT, "video_llava_amd", f)).read() for f in os.listdir(os.path.join(ROOT, "video_llava_amd")) if f.endswith(".py") and f != "build.py")
+    assert "libpgv_ubsan" not in src and "build_sanitizer" not in src
+
+
 def test_no_kernel_spills_to_scratch():
     """Every gfx950 kernel of libpgv must fit its registers: a spilled accumulator or DMA offset inside a GEMM/attention loop
     costs 2-3x (seen while building the 4-wave GEMM), so scratch use is a build failure, not a perf note."""

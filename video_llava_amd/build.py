@@ -40,9 +40,35 @@ LAB_OBJ = os.path.join(HERE, "_build_lab")
 LAB_LIB = os.path.join(HERE, "libpgv_lab.so")     # -DPGV_LAB: timing-ablation switches compiled in (results are garbage under them); never loaded by the product
 
 
-def build_variant(name: str, defines: list[str], verbose: bool = False, csrc: str | None = None) -> str:
+SANITIZER_FLAGS = ["-fsanitize=undefined", "-fno-sanitize=vptr", "-fno-sanitize-recover=undefined", "-shared-libsan", "-fno-gpu-sanitize", "-fno-omit-frame-pointer", "-g",
+                   "-D_GLIBCXX_ASSERTIONS"]
+
+
+def sanitizer_runtime() -> str:
+    """Path of the UBSan runtime that must be LD_PRELOADed into python to load libpgv_ubsan.so."""
+    for c in (os.path.join(os.path.dirname(os.path.realpath(_hipcc())), "..", "lib", "llvm", "bin", "clang"), "/opt/rocm/lib/llvm/bin/clang"):
+        if os.path.exists(c):
+            r = subprocess.run([c, "-print-file-name=libclang_rt.ubsan_standalone-x86_64.so"], capture_output=True, text=True)
+            if r.returncode == 0 and os.path.exists(r.stdout.strip()):
+                return r.stdout.strip()
+    raise RuntimeError("libclang_rt.ubsan_standalone-x86_64.so not found in the ROCm toolchain")
+
+
+def build_sanitizer(verbose: bool = False) -> str:
+    """SURVEY.md 5 (aux, "new"): a sanitizer build of the HOST side of libpgv -- weight packing, row maps, workspace arena, graph capture,
+    C-ABI argument handling -- as libpgv_ubsan.so: UndefinedBehaviorSanitizer (non-recoverable: the first report aborts the test) plus libstdc++'s
+    container assertions (every std::vector / std::string index of the host shim is bounds-checked) on the host code of every translation
+    unit; -fno-gpu-sanitize: the gfx950 kernels are the release kernels.  Run the GPU tests under it with scripts/sessions/r4_ubsan.sh
+    (LD_PRELOAD of sanitizer_runtime() + scripts/lab/with_lib.py).  Never loaded by the product.
+    AddressSanitizer is not usable here: ROCm's ASan runtime intercepts hsa_amd_memory_pool_allocate and aborts inside the HIP runtime that
+    torch bundles ("allocator is trying to allocate 0x400000 bytes", before any libpgv code runs; gpurun_out/r4asan2, r4asan3)."""
+    return build_variant("ubsan", [], verbose=verbose, extra_flags=SANITIZER_FLAGS)
+
+
+def build_variant(name: str, defines: list[str], verbose: bool = False, csrc: str | None = None, extra_flags: list[str] | None = None) -> str:
     """Lab A/B builds: libpgv_<name>.so compiled with extra -D flags (objects under _build_<name>/), optionally from another source
     directory (e.g. `git worktree` of an older commit's csrc).  Bound only by scripts/lab/with_lib.py."""
+    extra_flags = extra_flags or []
     CSRC = csrc or globals()["CSRC"]
     odir = os.path.join(HERE, f"_build_{name}")
     os.makedirs(odir, exist_ok=True)
@@ -50,14 +76,15 @@ def build_variant(name: str, defines: list[str], verbose: bool = False, csrc: st
     objs = []
     def one(src):
         opath = os.path.join(odir, src.replace(".hip", ".o"))
-        cmd = [_hipcc(), *FLAGS, *[f"-D{d}" for d in defines], *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", opath]
+        cmd = [_hipcc(), *FLAGS, *extra_flags, *[f"-D{d}" for d in defines], *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", opath]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
         return opath
     with concurrent.futures.ThreadPoolExecutor(max_workers=8) as ex:
         objs = list(ex.map(one, [s_ for s_ in SOURCES if os.path.exists(os.path.join(CSRC, s_))]))
-    r = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs], capture_output=True, text=True)
+    link_extra = [f for f in extra_flags if f.startswith("-fsanitize") or f.startswith("-fno-sanitize") or f in ("-fno-gpu-sanitize", "-shared-libsan")]
+    r = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *link_extra, "-o", lib, *objs], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr}")
     return lib

@@ -85,6 +85,9 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(AttnArgs p) {
     // (conflict-free ds_read_b128 of one row per lane); V: chunk ^ (((row >> 1) & 1) << 2) (conflict-free transposing reads: the 32 lanes of
     // an LDS cycle touch 4 consecutive keys x 64 B, and rows two apart share banks).  Rows past N re-read the last row: their
     // probabilities are exactly 0 and the duplicated V values are finite.
+#ifndef PGV_LAB_ATTN_AUX
+#define PGV_LAB_ATTN_AUX 0              // cache-policy bits of the K / V staging loads (every byte is read once, by one workgroup): lab A/B
+#endif
     {
         const int srow = lane >> 3, slot = lane & 7;
         for (int g = w; g < npad / 8; g += nw) {
@@ -93,12 +96,12 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(AttnArgs p) {
             if (!(PGV_ATTN_ABL(p) & 4)) {
                 const int chunk = slot ^ ((row >> 1) & 7);
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + ((row0 + rr) * p.ld + chunk * 8) * 2),
-                                                 (__attribute__((address_space(3))) void*)(Ks + g * 1024), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(Ks + g * 1024), 16, 0, PGV_LAB_ATTN_AUX);
             }
             if (!(PGV_ATTN_ABL(p) & 1)) {
                 const int chunk = slot ^ (((row >> 1) & 1) << 2);
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + ((row0 + rr) * p.ld + chunk * 8) * 2),
-                                                 (__attribute__((address_space(3))) void*)(Vs + g * 1024), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void*)(Vs + g * 1024), 16, 0, PGV_LAB_ATTN_AUX);
             }
         }
     }
