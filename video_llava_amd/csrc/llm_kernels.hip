@@ -289,6 +289,7 @@ struct GemvArgs {
     // batches beyond one MFMA tile (CT column tiles of 16 sequences, B <= 16 CT): every per-batch-column side array above is tile-major,
     // [CT][...][16], with these tile strides in elements
     int ssq_ts, amax_ts;
+    unsigned lds_bytes;                                        // gemv_k8_kernel: bytes of LDS for the x slice of one pass
     // A8 (the fp8 x fp8 MFMA form, PGV_FP8_MFMA=1): x is the hi / lo e4m3 image written by quant_hilo_kernel, xscale [B][2] its per-token scales
     const float* xscale;
 };
@@ -622,6 +623,134 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
             if (n0 + r < p.N) op[r] = tot[0][r];
     }
     }   // column tiles
+}
+
+// ---------------------------------------------------------------------------------------------
+// Residual producers (o_proj, down_proj) at decode batches beyond 16: a 2-D decomposition (round 4).
+// These matrices are narrow (N = hidden: 256 / 320 row blocks), so the 16-row kernel above puts ONE row block on a CU and every CU reads
+// the whole activation operand -- at 32 sequences twice the lines of its weights (down_proj 7B: 32.0 us at B = 32, 53.0 at 64, against
+// 19.2 at 16; LAB.md).  Here workgroup (grp, j) covers EIGHT row blocks (one per wave) x the K phase j of 8: wave p accumulates, for row
+// block 8 grp + p, exactly the 64-column groups j, j + 8, j + 16, ... in that order -- what wave j of the 16-row kernel accumulates for
+// that row block -- against x columns the whole workgroup shares through LDS (1/8 of x per workgroup instead of all of it).  The eight
+// phase tiles of a row block go to global memory and gemv_k8_finish_kernel adds them in phase order (the 16-row kernel's LDS reduce over
+// its waves 0..7) and runs the same epilogue: BITWISE the 16-row kernel's result, so a sequence is still independent of its batch.
+// NWB row blocks (= waves) per workgroup: 8.
+// ---------------------------------------------------------------------------------------------
+template <typename T, bool W8, int CT, int NWB>
+__global__ __launch_bounds__(NWB * 64) void gemv_k8_kernel(GemvArgs p, f32x4_t* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) char xs[];    // [groups of this pass][B rows][128 B], 16-B chunks XORed with (row & 7)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kg = lane >> 4;
+    const int j = blockIdx.x & 7, rb = ((int)blockIdx.x >> 3) * NWB + w;
+    const int kblocks = p.K >> 5, j_end = (kblocks + 1) >> 1;
+    const int gpw = (j_end - j + 7) >> 3;                        // groups of phase j: j, j + 8, ...
+    const int Brows = CT * 16;
+    const int gpp = max(1, min(gpw, (int)(p.lds_bytes / (Brows * 128))));   // groups per pass
+    using wreg_t = typename std::conditional<W8, u32x4_t, typename T::v8>::type;
+    constexpr int WH = W8 ? 1 : 2;
+    const char* wp = p.W + ((size_t)rb * (W8 ? (p.K >> 6) : kblocks)) * 1024 + lane * 16;
+    f32x4_t acc[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) acc[ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    constexpr int PU = 4;                                        // groups per register buffer
+    auto wload = [&](wreg_t (&wf)[PU][WH], int gi0) {
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+            const int g = min(j + 8 * (gi0 + u), j_end - 1);
+#pragma unroll
+            for (int h = 0; h < WH; ++h)
+                wf[u][h] = __builtin_nontemporal_load((const wreg_t*)(wp + (size_t)(W8 ? g : min(2 * g + h, kblocks - 1)) * 1024));
+        }
+    };
+    for (int pass0 = 0; pass0 < gpw; pass0 += gpp) {
+        const int ng = min(gpp, gpw - pass0);
+        wreg_t wa[PU][WH], wb[PU][WH];
+        wload(wa, pass0);                                        // the first weight batch is in flight while the x slice is staged
+        __syncthreads();                                         // the previous pass has been read by every wave
+        for (int c = tid; c < ng * Brows * 8; c += NWB * 64) {   // 16-byte chunks: (group, row, chunk)
+            const int ch = c & 7, row = (c >> 3) % Brows, gi = (c >> 3) / Brows;
+            const int g = j + 8 * (pass0 + gi), kb = 2 * g + (ch >> 2);
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if (row < p.B && kb < kblocks) v = *(const u32x4_t*)(p.x + ((size_t)row * p.ldx + (size_t)g * 64 + ch * 8) * 2);
+            *(u32x4_t*)(xs + ((size_t)(gi * Brows + row) * 128 + ((ch ^ (row & 7)) << 4))) = v;
+        }
+        __syncthreads();
+        auto mma = [&](wreg_t (&wf)[PU][WH], int gi0) {
+#pragma unroll
+            for (int u = 0; u < PU; ++u) {
+                const int gi = gi0 + u - pass0;
+                if (gi < ng) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        typename T::v8 wv;
+                        if constexpr (W8) wv = fp8x8_to_v8<T>(wf[u][0][2 * h], wf[u][0][2 * h + 1]);
+                        else wv = wf[u][h];
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct) {
+                            const int row = ct * 16 + l15;
+                            const typename T::v8 xv = *(const typename T::v8*)(xs + ((size_t)(gi * Brows + row) * 128 + (((h * 4 + kg) ^ (row & 7)) << 4)));
+                            acc[ct] = T::mfma16(wv, xv, acc[ct]);
+                        }
+                    }
+                }
+            }
+        };
+        int gi0 = pass0;
+        for (; gi0 + 2 * PU < pass0 + ng; gi0 += 2 * PU) {
+            wload(wb, gi0 + PU);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(wa, gi0);
+            __builtin_amdgcn_sched_barrier(0);
+            wload(wa, gi0 + 2 * PU);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(wb, gi0 + PU);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (gi0 + PU < pass0 + ng) {
+            wload(wb, gi0 + PU);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(wa, gi0);
+            mma(wb, gi0 + PU);
+        } else {
+            mma(wa, gi0);
+        }
+    }
+    f32x4_t* dst = part + (((size_t)rb * 8 + j) * CT) * 64 + lane;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) dst[ct * 64] = acc[ct];
+}
+
+// one wave per row block: the eight phase tiles in phase order, then the epilogue of gemv_mfma_kernel<GV_RESIDNORM> statement for statement
+template <typename T, bool W8, int CT>
+__global__ __launch_bounds__(64) void gemv_k8_finish_kernel(GemvArgs p, const f32x4_t* __restrict__ part) {
+    const int lane = threadIdx.x, l15 = lane & 15, kg = lane >> 4;
+    const int rb = blockIdx.x;
+    const int n0 = rb * 16 + kg * 4;
+    f32x4_t r_old[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) r_old[ct] = *(const f32x4_t*)(p.out + ((size_t)min(ct * 16 + l15, p.B - 1) * p.ldo + n0) * 4);
+    const f32x4_t g_nx = *(const f32x4_t*)(p.gamma + n0);
+    const f32x4_t* src = part + ((size_t)rb * 8 * CT) * 64 + lane;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        f32x4_t tot = src[(0 * CT + ct) * 64];
+#pragma unroll
+        for (int ww = 1; ww < 8; ++ww) tot += src[(ww * CT + ct) * 64];
+        if constexpr (W8) tot *= *(const f32x4_t*)(p.wscale + rb * 16 + kg * 4);
+        const int b = ct * 16 + l15;
+        float sq = 0.f;
+        if (b < p.B) {
+            f32x4_t* rp = (f32x4_t*)(p.out + ((size_t)b * p.ldo + n0) * 4);
+            const f32x4_t r = r_old[ct] + tot;
+            *rp = r;
+            const f32x4_t g = g_nx;
+            *(u32x2_t*)(p.xg + ((size_t)b * p.ldo + n0) * 2) = pack4<T>(r[0] * g[0], r[1] * g[1], r[2] * g[2], r[3] * g[3]);
+            sq = (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
+        }
+        sq = rows_sum_to_row3(sq);
+        if (kg == 3) p.ssq_out[(size_t)ct * p.ssq_ts + (size_t)rb * 16 + l15] = sq;
+    }
 }
 
 // Activation image of the fp8 x fp8 form: x [B][K] 16-bit -> x8 [B][K / 8][16 B] (8 hi codes, 8 lo codes per 8 consecutive k: the 16-bit
@@ -1323,7 +1452,7 @@ int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void
     GemvArgs a;
     a.W = (const char*)W; a.x = (const char*)x; a.out = (char*)out; a.N = N; a.K = K; a.B = B; a.ldx = ldx; a.ldo = ldo; a.wscale = wscale;
     a.ssq_in = nullptr; a.nparts_in = 0; a.inv_h = 0.f; a.eps = 0.f; a.gamma = nullptr; a.xg = nullptr; a.ssq_out = nullptr; a.amax_val = nullptr; a.amax_idx = nullptr;
-    a.ssq_ts = 0; a.amax_ts = 0; a.xscale = xscale;
+    a.ssq_ts = 0; a.amax_ts = 0; a.xscale = xscale; a.lds_bytes = 0;
     PGV_CHECK(xscale == nullptr || (w8 && B <= 16 && mode != GV_RESID), "gemv: the fp8 x fp8 form needs fp8 weights, at most 16 sequences and a folded-norm mode");
     PGV_CHECK(B <= 16 || norm == nullptr || (norm->ssq_ts > 0 && (norm->amax_val == nullptr || norm->amax_ts > 0)), "gemv: batches beyond 16 need the tile strides of the side arrays");
     if (norm) {
@@ -1359,7 +1488,31 @@ int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void
             case GV_RESID: PGV_GEMV_WIDE(GV_RESID, 1, grid); break;
             case GV_SWIGLU: if (grid % 2 == 0 && B <= 32) PGV_GEMV_W(GV_SWIGLU, 4, 2, grid / 2); else PGV_GEMV_WIDE(GV_SWIGLU, 2, grid); break;   // (4 row blocks x 4 column tiles spill)
             case GV_F32: PGV_GEMV_WIDE(GV_F32, 1, grid); break;
-            case GV_RESIDNORM: PGV_GEMV_WIDE(GV_RESIDNORM, 1, grid); break;
+            case GV_RESIDNORM: {
+                // narrow matrices: 8 row blocks x K phase per workgroup + a finish launch (gemv_k8_kernel) when the scratch is there
+                static int k8 = -1;
+                if (k8 < 0) { const char* e = getenv("PGV_GEMV_K8"); k8 = (e && e[0] == '0') ? 0 : 1; }
+                if (k8 && norm && norm->k8_part && grid % 8 == 0 && (K / 64) >= 16) {
+                    const int ct = B <= 32 ? 2 : 4;
+                    const int gpw_max = ((K / 32 + 1) / 2 + 7) / 8;
+                    const unsigned budget = 96u * 1024u, per_group = (unsigned)ct * 16u * 128u;
+                    unsigned lds = (unsigned)gpw_max * per_group;
+                    if (lds > budget) lds = budget / per_group * per_group;
+                    a.lds_bytes = lds;
+                    f32x4_t* part = (f32x4_t*)norm->k8_part;
+#define PGV_K8(W8_, CT_, NWB_) do { \
+                    static bool cfg_done = false; \
+                    if (!cfg_done) { PGV_HIP(hipFuncSetAttribute((const void*)gemv_k8_kernel<TF16, W8_, CT_, NWB_>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304)); \
+                                     PGV_HIP(hipFuncSetAttribute((const void*)gemv_k8_kernel<TBF16, W8_, CT_, NWB_>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304)); cfg_done = true; } \
+                    PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gemv_k8_kernel<T, W8_, CT_, NWB_>), dim3(grid / NWB_ * 8), dim3(NWB_ * 64), lds, s, a, part)); \
+                    PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gemv_k8_finish_kernel<T, W8_, CT_>), dim3(grid), dim3(64), 0, s, a, (const f32x4_t*)part)); } while (0)
+                    // (4 row blocks per workgroup, two workgroups per CU: 29.6 us per launch against 28.0 at 32 clips, gpurun_out/r4p)
+                    if (w8) { if (ct == 2) PGV_K8(true, 2, 8); else PGV_K8(true, 4, 8); }
+                    else { if (ct == 2) PGV_K8(false, 2, 8); else PGV_K8(false, 4, 8); }
+#undef PGV_K8
+                } else PGV_GEMV_WIDE(GV_RESIDNORM, 1, grid);
+                break;
+            }
             default: pgv_set_error("gemv: bad mode %d", mode); return PGV_EINVAL;
         }
         pgv_prof_end(ctx, 3, s, 2.0 * B * (double)N * K, (w8 ? 1.0 : 2.0) * (double)N * K);
