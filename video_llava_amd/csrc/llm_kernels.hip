@@ -1492,7 +1492,9 @@ int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void
                 // narrow matrices: 8 row blocks x K phase per workgroup + a finish launch (gemv_k8_kernel) when the scratch is there
                 static int k8 = -1;
                 if (k8 < 0) { const char* e = getenv("PGV_GEMV_K8"); k8 = (e && e[0] == '0') ? 0 : 1; }
-                if (k8 && norm && norm->k8_part && grid % 8 == 0 && (K / 64) >= 16) {
+                // where it pays (kernel trace at 32 clips, gpurun_out/r4q): down_proj 32.0 -> 22.4 + 4.9 us (finish), o_proj 13.3 -> 9.6 + 4.9: the
+                // short-K matrix only gains once the batch spans four column tiles
+                if (k8 && norm && norm->k8_part && grid % 8 == 0 && (K / 64) >= 16 && (B > 32 || K >= 8192)) {
                     const int ct = B <= 32 ? 2 : 4;
                     const int gpw_max = ((K / 32 + 1) / 2 + 7) / 8;
                     const unsigned budget = 96u * 1024u, per_group = (unsigned)ct * 16u * 128u;
