@@ -23,6 +23,7 @@ timeout 600 python bench.py $S --workload vision --steps 10 --warmup 3 > $O/benc
 timeout 600 python bench.py $S --image 336 > $O/bench_image336.json 2> $O/bench_image336.err
 timeout 600 python bench.py $S --clips-per-gpu 16 > $O/bench_clips16.json 2> $O/bench_clips16.err
 timeout 600 python bench.py $S --clips-per-gpu 64 --steps 2 > $O/bench_clips64.json 2> $O/bench_clips64.err
+timeout 600 python bench.py $S --clips-per-gpu 32 --steps 2 > $O/bench_clips32.json 2> $O/bench_clips32.err
 timeout 600 python bench.py $S --clips-per-gpu 32 --weights fp8 --steps 2 > $O/bench_clips32_fp8.json 2> $O/bench_clips32_fp8.err
 PGV_FP8_MFMA=1 timeout 900 python bench.py $S --weights fp8 --llm 13b > $O/bench_13b_fp8_mfma.json 2> $O/bench_13b_fp8_mfma.err
 # config 5 as a measured path of its own: kernel trace + PMC of the 13B fp8 line
@@ -35,7 +36,7 @@ timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/write5 -o pmc -- pyt
 python scripts/pmc_summary.py $O/fetch5/pmc_results.db $O/write5/pmc_results.db $O/pmc_traffic_13b_fp8.json > $O/pmc_traffic_13b_fp8.txt 2>&1
 rm -rf $O/fetch5 $O/write5
 (PGV_BENCH_SHARE_DEVICE=1 PGV_DIST_BACKEND=gloo timeout 400 python bench.py --gpus 2 --steps 2 --warmup 1 --no-host-frames --no-latency --no-profile-pass > $O/bench_gpus2_shared.log 2>&1; echo rc=$? >> $O/bench_gpus2_shared.log)
-for f in bench bench_7b_fp8 bench_13b_bf16 bench_vision_only bench_image336 bench_clips16 bench_clips64 bench_clips32_fp8 bench_13b_fp8_mfma; do python - $O/$f.json <<'PY'
+for f in bench bench_7b_fp8 bench_13b_bf16 bench_vision_only bench_image336 bench_clips16 bench_clips32 bench_clips64 bench_clips32_fp8 bench_13b_fp8_mfma; do python - $O/$f.json <<'PY'
 import json,sys
 try:
     d=json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
