@@ -3,7 +3,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out/pmc_sq
-ARGS="--steps 1 --warmup 0 --new-tokens 9 --no-cpu-baseline --no-profile-pass"
+ARGS="--steps 1 --warmup 0 --new-tokens 9 --no-cpu-baseline --no-profile-pass --no-host-frames --no-latency --no-runner --no-side"
 i=0
 for grp in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL SQ_LDS_ADDR_CONFLICT" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM" "SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_MFMA"; do
   i=$((i+1))

@@ -5,7 +5,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 mkdir -p gpurun_out/pmc
-ARGS="--steps 1 --warmup 0 --new-tokens 9 --no-cpu-baseline --no-profile-pass"
+ARGS="--steps 1 --warmup 0 --new-tokens 9 --no-cpu-baseline --no-profile-pass --no-host-frames --no-latency --no-runner --no-side"
 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/pmc/fetch -o pmc -- python bench.py $ARGS > gpurun_out/pmc/fetch.json 2> gpurun_out/pmc/fetch.err
 timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/pmc/write -o pmc -- python bench.py $ARGS > gpurun_out/pmc/write.json 2> gpurun_out/pmc/write.err
 ls -la gpurun_out/pmc/fetch gpurun_out/pmc/write
