@@ -133,6 +133,32 @@ def test_ragged_batch_random_shapes(ctx, seed):
         assert batch[i, len(p):len(p) + n].tolist() == single, (seed, B, i, len(p))
 
 
+@pytest.mark.parametrize("B", [17, 32, 33, 48, 64])
+def test_wide_batch_tile_edges(ctx, B):
+    """Batch sizes on both sides of every MFMA column-tile boundary (16 / 32 / 48): the kernels run 2 or 4 tiles and write every tile's slice of
+    the tile-major side arrays, also for tiles that hold no sequence (B = 33 ran 4 tiles over arrays sized for 3 in a first version and
+    faulted).  Greedy tokens of the batch through the graph-replayed device loop == single-sequence runs, and a second generate() on the same
+    model with another batch size right after (cache and side arrays re-created) still agrees."""
+    cfg = synth.LLAMA_TINY
+    w = synth.make_llama_weights(cfg, seed=3, head_std=0.08)
+    m = _model(cfg, w, torch.float16)
+    rng = np.random.default_rng(1000 + B)
+    PATCH, START, END = cfg.vocab - 3, cfg.vocab - 2, cfg.vocab - 1
+    V = 20
+    prompts = [[1] + rng.integers(1, cfg.vocab - 3, int(rng.integers(1, 90))).tolist() + [START] + [PATCH] * V + [END] + rng.integers(1, cfg.vocab - 3, 3).tolist()
+               for _ in range(B)]
+    feats_t = torch.from_numpy(rng.standard_normal((B, V, 1024), dtype=np.float32)).half()
+    n = 11
+    batch = m.generate(prompts, video_spatio_temporal_features=feats_t, max_new_tokens=n, chunk=4)
+    for i in (0, 15, 16, B - 1):
+        p = prompts[i]
+        single = m.generate([p], video_spatio_temporal_features=feats_t[i:i + 1], max_new_tokens=n)[0, len(p):].tolist()
+        assert batch[i, len(p):len(p) + n].tolist() == single, (B, i)
+    half = m.generate(prompts[:B // 2], video_spatio_temporal_features=feats_t[:B // 2], max_new_tokens=n)
+    for i in (0, B // 2 - 1):
+        assert half[i, len(prompts[i]):len(prompts[i]) + n].tolist() == batch[i, len(prompts[i]):len(prompts[i]) + n].tolist()
+
+
 TWO_LAYER_SEED = {"7b": 11, "13b": 8}      # 13B: margins 0.61 (fp16) / 0.50 (bf16)
 
 
