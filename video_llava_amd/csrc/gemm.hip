@@ -280,6 +280,124 @@ __device__ __forceinline__ void epilogue_w4(const KArgs& p, f32x16_t (&acc)[4][4
     }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Direct epilogue of the CLIP tower's three GEMMs (LayerNorm consumers qkv / fc1, producers out_proj / fc2): no LDS transpose.
+// For these instances the kernel feeds the MFMA unswapped (A fragment = activation rows), so a lane holds COLUMN lane & 31 of each 32-column
+// block and 16 rows (8 g + 4 hi + e) per accumulator tuple, and the W tile is DMAed with its rows permuted (LDS row 32 j + c of a wave's
+// 128-column slab <- W row 4 c + j; the permutation lives in the DMA source offsets and costs nothing): block j of lane c is output
+// column 4 c + j, so for one row the four tuples acc[i][0..3] give a lane 4 CONSECUTIVE columns and a half-wave 128 consecutive columns --
+// every store is 16 B (fp32) or 8 B (16-bit) per lane over whole 128-byte lines, straight from the accumulators.  Per-row values (LayerNorm
+// statistics, centres) are wave-uniform per (register, hi): loaded one K-step ahead (epi_direct_prefetch), parked in 1 KiB of the free
+// ring slot and read back as broadcast ds_read_b128.  Same arithmetic, element for element, as the staged epilogue above (the 16 lanes of a
+// DPP row still hold the 64 columns of a statistics piece in the same order): results are bitwise those of the staged form.
+// -------------------------------------------------------------------------------------------------
+template <int EPI>
+__device__ __forceinline__ void epi_direct_prefetch(const KArgs& p, int m0w, int lane, u32x2_t (&pf)[2]) {
+    const int rows_valid = max(0, min(128, p.M - m0w));
+    if constexpr (EPI == EPI_BIAS_RESID_LNOUT) {
+        // centres of rows lane and lane + 64 (a null rowmean gives a zero-size descriptor: loads return 0)
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.rowmean ? p.rowmean + m0w : (const float*)p.C, p.rowmean ? (unsigned)rows_valid * 4u : 0u);
+        pf[0][0] = __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)lane * 4u, 0, 0);
+        pf[1][0] = __builtin_amdgcn_raw_buffer_load_b32(rs, (unsigned)(lane + 64) * 4u, 0, 0);
+        pf[0][1] = 0; pf[1][1] = 0;
+    } else {
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(p.rowstat + (size_t)m0w * 2, (unsigned)rows_valid * 8u);
+        pf[0] = __builtin_amdgcn_raw_buffer_load_b64(rs, (unsigned)lane * 8u, 0, 0);
+        pf[1] = __builtin_amdgcn_raw_buffer_load_b64(rs, (unsigned)(lane + 64) * 8u, 0, 0);
+    }
+}
+
+template <typename T, int EPI>
+__device__ __forceinline__ void epilogue_direct(const KArgs& p, f32x16_t (&acc)[4][4], char* stg, int m0w, int n0w, int lane, const u32x2_t (&pf)[2]) {
+    constexpr bool LN_OUT = (EPI == EPI_BIAS_RESID_LNOUT);
+    constexpr int ES = LN_OUT ? 4 : 2;
+    const int l31 = lane & 31, hi = lane >> 5;
+    if constexpr (LN_OUT) { *(unsigned*)(stg + lane * 4) = pf[0][0]; *(unsigned*)(stg + 256 + lane * 4) = pf[1][0]; }
+    else { *(u32x2_t*)(stg + lane * 8) = pf[0]; *(u32x2_t*)(stg + 512 + lane * 8) = pf[1]; }
+    const int rows_valid = max(0, min(128, p.M - m0w));
+    const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(p.C + (size_t)m0w * p.ldc * ES, (unsigned)rows_valid * (unsigned)p.ldc * ES);
+    const unsigned rowpitch = (unsigned)p.ldc * ES;
+    const int col = n0w + 4 * l31;
+    const bool colok = col < p.N;
+    const unsigned voff = colok ? (unsigned)(4 * hi) * rowpitch + (unsigned)col * ES : OOB;
+    const f32x4_t bv = *(const f32x4_t*)(p.bias + min(col, p.N - 4));
+    const f32x4_t sv = *(const f32x4_t*)((LN_OUT ? p.gnext : p.colsum) + min(col, p.N - 4));      // LN_IN: column sums s_n;  LN_OUT: gamma of the next LayerNorm
+    __amdgpu_buffer_rsrc_t rs_x, rs_part;
+    unsigned voffx = 0, xpitch = 0;
+    float csh = 0.f;
+    if constexpr (LN_OUT) {
+        xpitch = (unsigned)p.ldx16 * 2u;
+        rs_x = make_rsrc(p.x16 + (size_t)m0w * p.ldx16 * 2, (unsigned)rows_valid * xpitch);
+        rs_part = make_rsrc(p.stats_part + (size_t)m0w * 2, (unsigned)(((size_t)(p.N >> 6) - 1) * p.M * 8 + (size_t)rows_valid * 8));
+        voffx = colok ? (unsigned)(4 * hi) * xpitch + (unsigned)col * 2u : OOB;
+        if (p.rowmean && p.cshift) csh = *p.cshift;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const char* srd = stg + hi * (LN_OUT ? 16 : 32);
+    u32x4_t old[8];                                            // LN_OUT: rolling window of fp32 residual rows, 8 rows ahead
+    if constexpr (LN_OUT) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) old[r] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + (unsigned)((r >> 2) * 8 + (r & 3)) * rowpitch, 0, PGV_LAB_EPI_AUX);
+    }
+    float keep1 = 0.f, keep2 = 0.f;
+#pragma unroll
+    for (int ig = 0; ig < 16; ++ig) {
+        const int i = ig >> 2, g = ig & 3;
+        const int rb = i * 32 + g * 8;                         // rows rb + 4 hi + e
+        __builtin_amdgcn_sched_barrier(0);                     // hipcc otherwise hoists the accumulator reads of two row blocks (132 registers) to the top
+        f32x4_t st01, st23, cmv;
+        if constexpr (LN_OUT) {
+            cmv = *(const f32x4_t*)(srd + rb * 4);
+        } else {
+            st01 = *(const f32x4_t*)(srd + rb * 8);            // (mean - centre, rstd) of rows e = 0, 1
+            st23 = *(const f32x4_t*)(srd + rb * 8 + 16);       // ... e = 2, 3
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned ro = (unsigned)(rb + e);
+            f32x4_t d;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(d[j]) : "a"(acc[i][j][g * 4 + e]));
+            if constexpr (!LN_OUT) {
+                const float mean = (e < 2 ? st01 : st23)[(e & 1) * 2], rstd = (e < 2 ? st01 : st23)[(e & 1) * 2 + 1];
+                const float a = rstd, c = -rstd * mean;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d[j] = a * d[j] + (c * sv[j] + bv[j]);               // rstd (acc - mean s_n) + b'_n
+                if constexpr (EPI == EPI_LN_BIAS_QGELU) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) d[j] = quick_gelu_f(d[j]);
+                }
+                __builtin_amdgcn_raw_buffer_store_b64(pack4<T>(d[0], d[1], d[2], d[3]), rsrc, voff + ro * rowpitch, 0, PGV_LAB_OUT16_AUX);
+            } else {
+                const int slot = (g & 1) * 4 + e;
+                const f32x4_t q = __builtin_bit_cast(f32x4_t, old[slot]);
+                if (ig + 2 < 16) {
+                    const int ig2 = ig + 2;
+                    old[slot] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + (unsigned)((ig2 >> 2) * 32 + (ig2 & 3) * 8 + e) * rowpitch, 0, PGV_LAB_EPI_AUX);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { d[j] += bv[j]; d[j] += q[j]; }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, d), rsrc, voff + ro * rowpitch, 0, PGV_LAB_EPI_AUX);
+                const float cm = cmv[e] + csh;
+                d[0] -= cm; d[1] -= cm; d[2] -= cm; d[3] -= cm;                                   // centred from here on (the fp32 residual above is not)
+                __builtin_amdgcn_raw_buffer_store_b64(pack4<T>(d[0] * sv[0], d[1] * sv[1], d[2] * sv[2], d[3] * sv[3]), rs_x, voffx + ro * xpitch, 0, 0);
+                // the 16 lanes of a DPP row hold the 64 columns of one statistics piece of this row: fold them (every lane gets the total);
+                // lane (l31 & 15) == 4 g + e keeps it, so after the 16 rows of block i lane (hi, piece, k) owns row i 32 + 8 (k >> 2) + 4 hi + (k & 3)
+                const float t1 = row16_sum((d[0] + d[1]) + (d[2] + d[3])), t2 = row16_sum((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]));
+                if ((l31 & 15) == g * 4 + e) { keep1 = t1; keep2 = t2; }
+            }
+        }
+        if constexpr (LN_OUT) {
+            if (g == 3) {
+                const int k = l31 & 15, row = i * 32 + 8 * (k >> 2) + 4 * hi + (k & 3);
+                const unsigned so = (row < rows_valid) ? (unsigned)row * 8u : OOB;
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, f32x2_t{keep1, keep2}), rs_part, so, (unsigned)((n0w >> 6) + (l31 >> 4)) * (unsigned)p.M * 8u, 0);
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <typename T, int EPI, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void gemm_w4(KArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -287,6 +405,11 @@ __global__ __launch_bounds__(256, 1) void gemm_w4(KArgs p) {
     // While step s is computed, step s+1 is resident and A(s+2) is landing in the fifth slot, so only HALF of a K-step's bytes
     // (W(s+2), issued right after the barrier that frees A(s)'s slot) has the one-K-step deadline; the other half has two.
     constexpr int BM = 256, BN = 256, SLOT = 32768;
+#ifdef PGV_LAB_STAGED_EPI
+    constexpr bool DIRECT = false;
+#else
+    constexpr bool DIRECT = (EPI == EPI_LN_BIAS || EPI == EPI_LN_BIAS_QGELU || EPI == EPI_BIAS_RESID_LNOUT);     // epilogue_direct: unswapped MFMA, permuted W rows
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -326,7 +449,9 @@ __global__ __launch_bounds__(256, 1) void gemm_w4(KArgs p) {
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int row = min(32 * j + 8 * w + srow, rows - 1);
+            int lrow = 32 * j + 8 * w + srow;                            // LDS row of the tile = 128 slab + 32 jb + c
+            if constexpr (DIRECT) lrow = 4 * (8 * w + srow) + (j >> 2) * 128 + (j & 3);           // ... holds W row 128 slab + 4 c + jb (epilogue_direct)
+            const int row = min(lrow, rows - 1);
             if (p.wblk) {
                 const int rw = n0 + row;                                 // 1 KiB block (rw/16, k/32); inside: slot ((k%32)/8)*16 + rw%16
                 voffW[j] = (unsigned)((((size_t)(rw >> 4) * (p.K >> 5) + (chunk >> 2)) * 512 + (((chunk & 3) << 4) + (rw & 15)) * 8) * 2);
@@ -405,8 +530,13 @@ __global__ __launch_bounds__(256, 1) void gemm_w4(KArgs p) {
         using Which = std::integral_constant<int, (dmasel >> 1)>;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-            mfma(first_c, acc[(2 * t) & 3][(2 * t) >> 2], fw[set][(2 * t) >> 2], fa[set][(2 * t) & 3]);
-            mfma(first_c, acc[(2 * t + 1) & 3][(2 * t + 1) >> 2], fw[set][(2 * t + 1) >> 2], fa[set][(2 * t + 1) & 3]);
+            if constexpr (DIRECT) {
+                mfma(first_c, acc[(2 * t) & 3][(2 * t) >> 2], fa[set][(2 * t) & 3], fw[set][(2 * t) >> 2]);
+                mfma(first_c, acc[(2 * t + 1) & 3][(2 * t + 1) >> 2], fa[set][(2 * t + 1) & 3], fw[set][(2 * t + 1) >> 2]);
+            } else {
+                mfma(first_c, acc[(2 * t) & 3][(2 * t) >> 2], fw[set][(2 * t) >> 2], fa[set][(2 * t) & 3]);
+                mfma(first_c, acc[(2 * t + 1) & 3][(2 * t + 1) >> 2], fw[set][(2 * t + 1) >> 2], fa[set][(2 * t + 1) & 3]);
+            }
             if constexpr (!(ABL & 2)) {
                 if (t < 4) fa[set ^ 1][t] = *(const typename T::v8*)(ra + a_off + t * 4096 + koffs[rkk]);
                 else fw[set ^ 1][t - 4] = *(const typename T::v8*)(rw + w_off + (t - 4) * 4096 + koffs[rkk]);
@@ -458,13 +588,24 @@ __global__ __launch_bounds__(256, 1) void gemm_w4(KArgs p) {
     }
     int stg_slot = 1;
     for (int vb = blockIdx.x; vb < total; vb += G) {
-        PGV_W4_KSTEP(First)                                           // C = 0 form on the first k slice: no zeroing pass
-        for (int kt = 1; kt < nk; ++kt) PGV_W4_KSTEP(Later)
         int tm, tn;
         tile_coords_v(vb, total, p.ntm, p.ntn, tm, tn);
-        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");             // last MFMA result -> first accumulator read
-        // staging = the slot of the W tile just consumed: free until the next K-step's G0 refills it
-        if constexpr (!(ABL & 32)) epilogue_w4<T, EPI>(p, acc, smem + stg_slot * SLOT + w * 8192, tm * BM + wr * 128, tn * BN + wc * 128, lane);
+        if constexpr (DIRECT) {
+            // the per-row values of the epilogue are fetched one K-step ahead (K >= 128 is checked at launch)
+            u32x2_t pf[2];
+            PGV_W4_KSTEP(First)
+            for (int kt = 1; kt < nk - 1; ++kt) PGV_W4_KSTEP(Later)
+            epi_direct_prefetch<EPI>(p, tm * BM + wr * 128, lane, pf);
+            PGV_W4_KSTEP(Later)
+            asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");         // last MFMA result -> first accumulator read
+            epilogue_direct<T, EPI>(p, acc, smem + stg_slot * SLOT + w * 8192, tm * BM + wr * 128, tn * BN + wc * 128, lane, pf);
+        } else {
+            PGV_W4_KSTEP(First)                                       // C = 0 form on the first k slice: no zeroing pass
+            for (int kt = 1; kt < nk; ++kt) PGV_W4_KSTEP(Later)
+            asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");         // last MFMA result -> first accumulator read
+            // staging = the slot of the W tile just consumed: free until the next K-step's G0 refills it
+            if constexpr (!(ABL & 32)) epilogue_w4<T, EPI>(p, acc, smem + stg_slot * SLOT + w * 8192, tm * BM + wr * 128, tn * BN + wc * 128, lane);
+        }
         __builtin_amdgcn_s_barrier();                                 // the next G0 refills the staging slot: every wave must be done with it
     }
 #undef PGV_W4_KSTEP
@@ -542,6 +683,7 @@ int pgv_launch_gemm(pgv_ctx* ctx, int dtype, const GemmArgs& a, hipStream_t s) {
     PGV_CHECK(a.lda % 8 == 0 && a.ldw % 8 == 0, "gemm: lda/ldw must be multiples of 8 elements");
     PGV_CHECK(((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.W & 15) == 0, "gemm: A/W must be 16-byte aligned");
     const bool out32 = (a.epi == PGV_EPI_RESID || a.epi == PGV_EPI_BIAS_RESID || a.epi == PGV_EPI_F32 || a.epi == EPI_BIAS_RESID_LNOUT);
+    if (a.epi == EPI_LN_BIAS || a.epi == EPI_LN_BIAS_QGELU || a.epi == EPI_BIAS_RESID_LNOUT) PGV_CHECK(!a.w_blocked && a.K >= 128, "gemm: the LayerNorm epilogues take row-major weights and K >= 128");
     if (a.epi == EPI_LN_BIAS || a.epi == EPI_LN_BIAS_QGELU) PGV_CHECK(a.rowstat && a.colsum && a.bias, "gemm: the LayerNorm-consumer epilogue needs rowstat / colsum / bias");
     if (a.epi == EPI_BIAS_RESID_LNOUT) PGV_CHECK(a.gnext && a.x16 && a.stats_part && a.N % 64 == 0 && a.ldx16 % 4 == 0, "gemm: the LayerNorm-producer epilogue needs gnext / x16 / stats_part and N %% 64 == 0");
     PGV_CHECK(((uintptr_t)a.C & (out32 ? 15 : 7)) == 0 && a.ldc % 4 == 0, "gemm: C misaligned (ptr/ldc)");
