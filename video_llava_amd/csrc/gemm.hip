@@ -364,8 +364,16 @@ __device__ __forceinline__ void epilogue_direct(const KArgs& p, f32x16_t (&acc)[
 #pragma unroll
                 for (int j = 0; j < 4; ++j) d[j] = a * d[j] + (c * sv[j] + bv[j]);               // rstd (acc - mean s_n) + b'_n
                 if constexpr (EPI == EPI_LN_BIAS_QGELU) {
+                    // quick_gelu_f on pairs: the scale and the + 1 as v_pk_mul_f32 / v_pk_add_f32 (same IEEE operations, half the instructions)
+                    const f32x2_t k2 = {-1.702f * 1.4426950408889634f, -1.702f * 1.4426950408889634f}, one2 = {1.0f, 1.0f};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) d[j] = quick_gelu_f(d[j]);
+                    for (int h = 0; h < 2; ++h) {
+                        const f32x2_t y = {d[2 * h], d[2 * h + 1]};
+                        const f32x2_t z = y * k2;
+                        const f32x2_t t = f32x2_t{__builtin_amdgcn_exp2f(z[0]), __builtin_amdgcn_exp2f(z[1])} + one2;
+                        const f32x2_t o = y * f32x2_t{__builtin_amdgcn_rcpf(t[0]), __builtin_amdgcn_rcpf(t[1])};
+                        d[2 * h] = o[0]; d[2 * h + 1] = o[1];
+                    }
                 }
                 __builtin_amdgcn_raw_buffer_store_b64(pack4<T>(d[0], d[1], d[2], d[3]), rsrc, voff + ro * rowpitch, 0, PGV_LAB_OUT16_AUX);
             } else {
