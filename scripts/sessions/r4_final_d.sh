@@ -15,7 +15,8 @@ timeout 600 python bench.py $S --workload vision --steps 10 --warmup 3 > $O/benc
 timeout 600 python bench.py $S --image 336 > $O/bench_image336.json 2> $O/bench_image336.err
 timeout 600 python bench.py $S --weights fp8 > $O/bench_7b_fp8.json 2> $O/bench_7b_fp8.err
 timeout 600 python bench.py $S --clips-per-gpu 64 --steps 2 > $O/bench_clips64.json 2> $O/bench_clips64.err
-for f in bench bench_under_rocprof bench_vision_only bench_image336 bench_7b_fp8 bench_clips64; do python - $O/$f.json <<'PY'
+for L in 1 2 3; do PGV_VIT_LANES=$L timeout 300 python bench.py $S --workload vision --steps 10 --warmup 3 > $O/bench_vision_lanes$L.json 2> $O/bench_vision_lanes$L.err; done
+for f in bench bench_under_rocprof bench_vision_lanes1 bench_vision_lanes2 bench_vision_lanes3 bench_vision_only bench_image336 bench_7b_fp8 bench_clips64; do python - $O/$f.json <<'PY'
 import json,sys
 try:
     d=json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
