@@ -267,6 +267,22 @@ def test_bench_launcher_dry_world2(launcher):
     assert d["clips_checked"] == 6
 
 
+@pytest.mark.parametrize("n", [4, 8])
+def test_bench_launcher_dry_world_4_8(n):
+    """The driver's scaling tier runs N = 1, 2, 4, 8: the same skeleton at 4 and 8 ranks (gloo, --dry) -- every clip of every rank lands in its
+    global slot on rank 0 and the per-rank step times are reported for all N ranks."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--dry", "--steps", "2", "--warmup", "1", "--clips-per-gpu", "2", "--new-tokens", "4"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == n and d["config"]["parallelism"] == f"dp{n}" and d["scaling"] == "weak"
+    assert d["collective"]["world_seen"] == n and d["clips_checked"] == 2 * n
+    assert len(d["collective"].get("rank_ms_per_step", [0] * n)) == n
+
+
 def test_bench_gpus_mismatch_is_loud():
     """A WORLD_SIZE that contradicts --gpus is an error, not a silently different run."""
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
