@@ -600,6 +600,49 @@ print("unfolded ok")
 
 
 
+def test_13b_fp8_down_proj_8_phase_form_is_bitwise_the_16_row_kernel(ctx):
+    """Config 5's down_proj (fp8, K = 13 824, 320 row blocks) runs the 8-phase residual producer also at batches <= 16
+    (llm_kernels.hip: w8 && K >= PGV_GEMV_K8_NARROW_MINK, default 12 288).  The form is a different launch shape of the same
+    arithmetic: prefill + 4 decode steps of a 13B-shaped 2-layer fp8 model at 1, 3 and 16 sequences must give the same logits BIT FOR BIT
+    with the threshold out of reach (the 16-row kernel) -- the switch is read once per process, so each setting runs in a child."""
+    import hashlib
+    import subprocess
+    import sys
+    code = f'''
+import sys, os, hashlib, numpy as np, torch
+sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r}); sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r})
+from oracle import synth
+from helpers import make_model
+cfg = synth.LlamaCfg(layers=2, hidden=5120, inter=13824, heads=40)
+w = synth.quantize_weights(synth.make_llama_weights(cfg, seed=8, head_std=0.05), "bfloat16")
+m = make_model(cfg, w, torch.bfloat16)
+m.quantize_weights_fp8()
+rng = np.random.default_rng(3)
+PATCH, START, END = cfg.vocab - 3, cfg.vocab - 2, cfg.vocab - 1
+V = 40
+h = hashlib.sha256()
+for B in (1, 3, 16):
+    prompts = [[1] + rng.integers(3, 32000, 20 + 3 * b).tolist() + [START] + [PATCH] * V + [END] + rng.integers(3, 32000, 5).tolist() for b in range(B)]
+    feats = torch.from_numpy(rng.standard_normal((B, V, 1024)).astype(np.float32)).to(torch.bfloat16).cuda()
+    kv, nxt, lg = m.prefill(prompts, feats, 128, want_logits=True)
+    h.update(lg.cpu().numpy().tobytes())
+    for _ in range(4):
+        nxt, lg = m.decode_step(kv, nxt, want_logits=True)
+        assert torch.isfinite(lg).all()
+        h.update(lg.cpu().numpy().tobytes()); h.update(nxt.cpu().numpy().tobytes())
+    kv2, nxt2, _ = m.prefill(prompts, feats, 128)
+    h.update(m.decode_greedy(kv2, nxt2, 9).cpu().numpy().tobytes())        # eager step + graph replays
+    del kv, kv2
+print("DIGEST", h.hexdigest())
+'''
+    digests = []
+    for mink in ("12288", "100000000"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, PGV_GEMV_K8_NARROW_MINK=mink))
+        assert r.returncode == 0 and "DIGEST" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+        digests.append(r.stdout.split("DIGEST")[1].split()[0])
+    assert digests[0] == digests[1], digests
+
+
 # --------------------------------------------------------------------------------------------------
 # fp8 x fp8 MFMA form of the decode GEMV (BASELINE configs[4] "fp8 MFMA weight path"; flag PGV_FP8_MFMA=1): activation = hi + lo e4m3
 # --------------------------------------------------------------------------------------------------

@@ -74,7 +74,7 @@ struct pgv_kv {
     float* amax_val; int* amax_idx;     // greedy candidates of the lm_head GEMV, tile-major: [ceil(B / 16)][vocab_cap / 16][16]
     float* ssq;                         // sum-of-squares partials of the folded RMSNorm, tile-major: [ceil(B / 16)][hidden / 16][16] (see GemvArgs in llm_kernels.hip)
     int ssq_ts, amax_ts;                // their tile strides in elements: hidden, vocab_cap
-    void* k8_part;                      // wide residual producers (llm_kernels.hip gemv_k8_kernel): phase tiles [hidden / 16][8][column tiles][64] float4; null for batches <= 16
+    void* k8_part;                      // 8-phase residual producers (llm_kernels.hip gemv_k8_kernel): phase tiles [hidden / 16][8][column tiles][64] float4
     void* x8; float* xscale;            // fp8 x fp8 MFMA form (PGV_FP8_MFMA=1): hi / lo e4m3 image of the current GEMV's activation operand [B][max(hidden, inter)] x 2 B, scales [B][2]
     float* dattn_part; unsigned* dattn_ticket;   // context-split decode attention: partial states [B * heads][8][130], arrival tickets [B * heads] (zero between launches)
     int *d_pos, *d_cur, *d_step, *d_done, *d_hist;
@@ -307,7 +307,7 @@ extern "C" int pgv_kv_create(pgv_ctx* ctx, pgv_llm* llm, int batch, int max_seq,
     const size_t o_resid = take(B * H * 4), o_xn = take(B * H * 2), o_qkv = take(B * 3 * H * 2), o_ao = take(B * H * 2), o_act = take(B * I * 2),
                  o_logits = take(B * V * 4), o_ssq = take(CTn * H * 4), o_av = take(CTn * V * 4), o_ai = take(CTn * V * 4), o_ints = take((4 * B + B * (size_t)max_seq) * 4),
                  o_u = take(B * (size_t)max_seq * 4), o_dpart = take(B * llm->cfg.heads * (size_t)kDattnSplitMax * kDattnPart * 4), o_dtick = take(B * llm->cfg.heads * 4),
-                 o_x8 = take(B * (I > H ? I : H) * 2), o_xs = take(B * 2 * 4), o_k8 = take(B > 16 ? (H / 16) * 8 * CTn * 64 * 16 : 0);
+                 o_x8 = take(B * (I > H ? I : H) * 2), o_xs = take(B * 2 * 4), o_k8 = take((H / 16) * 8 * CTn * 64 * 16);
     hipError_t e = hipMalloc((void**)&kv->blob, off);
     if (e != hipSuccess) { delete kv; pgv_set_error("pgv_kv_create: hipMalloc(%zu MiB): %s", off >> 20, hipGetErrorString(e)); return PGV_ENOMEM; }
     char* b = kv->blob;
@@ -317,7 +317,7 @@ extern "C" int pgv_kv_create(pgv_ctx* ctx, pgv_llm* llm, int batch, int max_seq,
     kv->d_pos = ints; kv->d_cur = ints + B; kv->d_step = ints + 2 * B; kv->d_done = ints + 3 * B; kv->d_hist = ints + 4 * B;
     kv->d_u = (float*)(b + o_u);
     kv->dattn_part = (float*)(b + o_dpart); kv->dattn_ticket = (unsigned*)(b + o_dtick);
-    kv->x8 = b + o_x8; kv->xscale = (float*)(b + o_xs); kv->k8_part = B > 16 ? (void*)(b + o_k8) : nullptr;
+    kv->x8 = b + o_x8; kv->xscale = (float*)(b + o_xs); kv->k8_part = (void*)(b + o_k8);
     e = hipMemset(ints, 0, (4 * B + B * (size_t)max_seq) * 4);
     if (e == hipSuccess) e = hipMemset(kv->dattn_ticket, 0, B * llm->cfg.heads * 4);
     if (e == hipSuccess) e = hipMemset(kv->ssq, 0, CTn * H * 4);

@@ -1444,6 +1444,31 @@ int pgv_launch_quant_hilo(int dtype, const void* x, int ldx, int K, int B, void*
     return PGV_OK;
 }
 
+// The 8-phase form of a residual producer (gemv_k8_kernel + gemv_k8_finish_kernel) with CT column tiles; `a` is complete except lds_bytes.
+template <bool W8, int CT>
+static int launch_k8(int dtype, GemvArgs a, int grid, void* k8_part, hipStream_t s) {
+    const int gpw_max = ((a.K / 32 + 1) / 2 + 7) / 8;
+    const unsigned budget = 96u * 1024u, per_group = (unsigned)CT * 16u * 128u;
+    unsigned lds = (unsigned)gpw_max * per_group;
+    if (lds > budget) lds = budget / per_group * per_group;
+    a.lds_bytes = lds;
+    f32x4_t* part = (f32x4_t*)k8_part;
+    static bool cfg_done = false;
+    if (!cfg_done) {
+        PGV_HIP(hipFuncSetAttribute((const void*)gemv_k8_kernel<TF16, W8, CT, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
+        PGV_HIP(hipFuncSetAttribute((const void*)gemv_k8_kernel<TBF16, W8, CT, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
+        cfg_done = true;
+    }
+    PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gemv_k8_kernel<T, W8, CT, 8>), dim3(grid), dim3(512), lds, s, a, part));
+    PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gemv_k8_finish_kernel<T, W8, CT>), dim3(grid), dim3(64), 0, s, a, (const f32x4_t*)part));
+    return PGV_OK;
+}
+static bool k8_enabled() {
+    static int k8 = -1;
+    if (k8 < 0) { const char* e = getenv("PGV_GEMV_K8"); k8 = (e && e[0] == '0') ? 0 : 1; }
+    return k8 == 1;
+}
+
 int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void* x, int ldx, void* out, int ldo, int N, int K, int B, hipStream_t s,
                     const float* wscale, const GemvNorm* norm, const float* xscale) {
     PGV_CHECK(B >= 1 && B <= 64, "gemv: batch %d outside [1,64]", B);
@@ -1490,28 +1515,12 @@ int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void
             case GV_F32: PGV_GEMV_WIDE(GV_F32, 1, grid); break;
             case GV_RESIDNORM: {
                 // narrow matrices: 8 row blocks x K phase per workgroup + a finish launch (gemv_k8_kernel) when the scratch is there
-                static int k8 = -1;
-                if (k8 < 0) { const char* e = getenv("PGV_GEMV_K8"); k8 = (e && e[0] == '0') ? 0 : 1; }
                 // where it pays (kernel trace at 32 clips, gpurun_out/r4q): down_proj 32.0 -> 22.4 + 4.9 us (finish), o_proj 13.3 -> 9.6 + 4.9: the
                 // short-K matrix only gains once the batch spans four column tiles
-                if (k8 && norm && norm->k8_part && grid % 8 == 0 && (K / 64) >= 16 && (B > 32 || K >= 8192)) {
-                    const int ct = B <= 32 ? 2 : 4;
-                    const int gpw_max = ((K / 32 + 1) / 2 + 7) / 8;
-                    const unsigned budget = 96u * 1024u, per_group = (unsigned)ct * 16u * 128u;
-                    unsigned lds = (unsigned)gpw_max * per_group;
-                    if (lds > budget) lds = budget / per_group * per_group;
-                    a.lds_bytes = lds;
-                    f32x4_t* part = (f32x4_t*)norm->k8_part;
-#define PGV_K8(W8_, CT_, NWB_) do { \
-                    static bool cfg_done = false; \
-                    if (!cfg_done) { PGV_HIP(hipFuncSetAttribute((const void*)gemv_k8_kernel<TF16, W8_, CT_, NWB_>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304)); \
-                                     PGV_HIP(hipFuncSetAttribute((const void*)gemv_k8_kernel<TBF16, W8_, CT_, NWB_>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304)); cfg_done = true; } \
-                    PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gemv_k8_kernel<T, W8_, CT_, NWB_>), dim3(grid / NWB_ * 8), dim3(NWB_ * 64), lds, s, a, part)); \
-                    PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gemv_k8_finish_kernel<T, W8_, CT_>), dim3(grid), dim3(64), 0, s, a, (const f32x4_t*)part)); } while (0)
-                    // (4 row blocks per workgroup, two workgroups per CU: 29.6 us per launch against 28.0 at 32 clips, gpurun_out/r4p)
-                    if (w8) { if (ct == 2) PGV_K8(true, 2, 8); else PGV_K8(true, 4, 8); }
-                    else { if (ct == 2) PGV_K8(false, 2, 8); else PGV_K8(false, 4, 8); }
-#undef PGV_K8
+                // (4 row blocks per workgroup, two workgroups per CU: 29.6 us per launch against 28.0 at 32 clips, gpurun_out/r4p)
+                if (k8_enabled() && norm && norm->k8_part && grid % 8 == 0 && (K / 64) >= 16 && (B > 32 || K >= 8192)) {
+                    if (w8) { if (B <= 32) PGV_TRY((launch_k8<true, 2>(dtype, a, grid, norm->k8_part, s))); else PGV_TRY((launch_k8<true, 4>(dtype, a, grid, norm->k8_part, s))); }
+                    else { if (B <= 32) PGV_TRY((launch_k8<false, 2>(dtype, a, grid, norm->k8_part, s))); else PGV_TRY((launch_k8<false, 4>(dtype, a, grid, norm->k8_part, s))); }
                 } else PGV_GEMV_WIDE(GV_RESIDNORM, 1, grid);
                 break;
             }
@@ -1551,7 +1560,15 @@ int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void
         case GV_RESID: PGV_GEMV(GV_RESID, 8, 1, 2, 4, 4, grid); break;
         case GV_SWIGLU: PGV_GEMV(GV_SWIGLU, 8, 2, 1, 2, 2, grid); break;
         case GV_F32: PGV_GEMV(GV_F32, 8, 1, 2, 4, 4, grid); break;
-        case GV_RESIDNORM: PGV_GEMV(GV_RESIDNORM, 8, 1, 2, 4, 4, grid); break;
+        case GV_RESIDNORM: {
+            // fp8 down_proj of the 13B shapes (K = 13 824, 320 row blocks): a 16-row workgroup requests as many activation lines as weight lines
+            // (LAB.md "what the activation operand costs"); the 8-phase form reads 1/8 of x per workgroup and is bitwise the same result
+            static int mink = -1;
+            if (mink < 0) { const char* e = getenv("PGV_GEMV_K8_NARROW_MINK"); mink = e ? atoi(e) : 12288; }
+            if (w8 && k8_enabled() && norm && norm->k8_part && grid % 8 == 0 && K >= mink) PGV_TRY((launch_k8<true, 1>(dtype, a, grid, norm->k8_part, s)));
+            else PGV_GEMV(GV_RESIDNORM, 8, 1, 2, 4, 4, grid);
+            break;
+        }
         default: pgv_set_error("gemv: bad mode %d", mode); return PGV_EINVAL;
     }
 #undef PGV_GEMV
