@@ -570,9 +570,11 @@ def main_dry(args):
 
 class Workload:
     """One configuration of the hot path on this rank's GPU: random-init tower + decoder of the named shapes, synthetic frames resident in HBM,
-    ActivityNet-QA-shaped prompts.  `a` carries dtype / llm / weights / image / workload / clips_per_gpu / frames / new_tokens."""
+    ActivityNet-QA-shaped prompts.  `a` carries dtype / llm / weights / image / workload / clips_per_gpu / frames / new_tokens.
+    `tower` / `model`: prebuilt objects with weights already loaded (tests/test_gpu_fulldepth.py drives `step` -- the call this file times --
+    on seeded weights the CPU oracle also holds); by default both are built here with random-init weights."""
 
-    def __init__(self, a, dev, rank, world):
+    def __init__(self, a, dev, rank, world, tower=None, model=None):
         from video_llava_amd import _lib, parallel
         from video_llava_amd import random_init as ri
         from video_llava_amd.model.video_chatgpt import VideoChatGPTConfig, VideoChatGPTLlamaForCausalLM, VisionConfig
@@ -584,12 +586,14 @@ class Workload:
         S = self.S
         self.video_rows = 100 + (S // 14) ** 2                      # 356 at 224 px, 676 at 336 px
         self.projector = "linear" if S == 224 else "mlp2x_gelu"    # reference rule: model/video_chatgpt.py:52-55
-        self.tower = CLIPVisionTower(CLIPVisionTowerConfig(image_size=S), dtype, dev)
-        ri.load_streaming(self.tower, ri.iter_clip_tensors(image=S, device=dev, dtype=dtype, seed=1))
+        self.tower = tower
+        if tower is None:
+            self.tower = CLIPVisionTower(CLIPVisionTowerConfig(image_size=S), dtype, dev)
+            ri.load_streaming(self.tower, ri.iter_clip_tensors(image=S, device=dev, dtype=dtype, seed=1))
         shapes = dict(hidden=4096, inter=11008, layers=32, heads=32) if a.llm == "7b" else dict(hidden=5120, inter=13824, layers=40, heads=40)
         self.vocab = vocab = 32003
-        self.model = self.proj = None
-        if a.workload == "full":
+        self.model, self.proj = model, None
+        if a.workload == "full" and model is None:
             cfg = VideoChatGPTConfig(vocab_size=vocab, hidden_size=shapes["hidden"], intermediate_size=shapes["inter"],
                                      num_hidden_layers=shapes["layers"], num_attention_heads=shapes["heads"], eos_token_id=None,
                                      mm_projector_type=self.projector)
@@ -600,7 +604,7 @@ class Workload:
             vc.vid_patch_token, vc.vid_start_token, vc.vid_end_token, vc.use_vid_start_end = vocab - 3, vocab - 2, vocab - 1, True
             if a.weights == "fp8":
                 self.model.quantize_weights_fp8()
-        else:
+        elif a.workload != "full":
             from video_llava_amd.model.multimodal_projector.builder import HipLinear
             self.proj = HipLinear(1024, 4096, dtype, dev)
             self.proj.weight.data.normal_(0, 0.02); self.proj.bias.data.normal_(0, 0.02)
@@ -786,6 +790,10 @@ def main():
     from video_llava_amd import _lib, parallel
     from video_llava_amd.inference import get_spatio_temporal_features_torch
 
+    if torch.cuda.is_available() and not os.environ.get("PGV_BENCH_SHARE_DEVICE"):
+        # host threads of this rank (prefetch, OMP, the process-group backend's own) next to its GPU: BEFORE the backend starts its threads;
+        # silent when sysfs says nothing.  (With one shared device every rank would pin to the same GPU's slice: skipped.)
+        parallel.pin_rank_to_numa_node(int(os.environ.get("LOCAL_RANK", "0")))
     rank, world, local = parallel.init_distributed()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
@@ -796,7 +804,6 @@ def main():
                          "PGV_BENCH_SHARE_DEVICE=1 PGV_DIST_BACKEND=gloo runs the ranks on one device as a control-flow check)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    parallel.pin_rank_to_numa_node(local)                 # host threads of this rank (prefetch, OMP) next to its GPU; silent when sysfs says nothing
     wl = Workload(args, dev, rank, world)
     ctx, model, tower, frames, prompts = wl.ctx, wl.model, wl.tower, wl.frames, wl.prompts
     B, T, NEW, S, vocab, n_global, mine = wl.B, wl.T, wl.NEW, wl.S, wl.vocab, wl.n_global, wl.mine

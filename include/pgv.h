@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PGV_VERSION 210
+#define PGV_VERSION 300
 
 enum { PGV_OK = 0, PGV_EINVAL = 1, PGV_EHIP = 2, PGV_ENOMEM = 3, PGV_ESTATE = 4, PGV_ENAME = 5 };
 enum { PGV_F16 = 0, PGV_BF16 = 1, PGV_F32 = 2 };
@@ -237,15 +237,6 @@ int pgv_quantize_fp8_blocked(pgv_ctx *ctx, int dtype, void *d_w16_blocked, void 
 /* pgv_gemv on the fp8 copy: bit-identical to pgv_gemv on the dequantised 16-bit matrix, half the weight bytes.  modes 0..3. */
 int pgv_gemv_fp8(pgv_ctx *ctx, int dtype, int mode, const void *d_W8, const float *d_scales, const void *d_x, int ldx, void *d_out, int ldo,
                  int N, int K, int B, void *stream);
-/* The fp8 x fp8 MFMA form of the decode GEMV (BASELINE configs[4] names an "fp8 MFMA weight path"; selected inside pgv_llm_decode* by
- * PGV_FP8_MFMA=1, otherwise the weight-only form above runs).  pgv_quantize_act_hilo writes the activation image the kernel consumes:
- * x [B, K] 16-bit (row stride ldx) -> d_x8 [B, K / 8, 16 bytes] = 8 "hi" + 8 "lo" e4m3 codes per 8 consecutive k, and d_xscales [B, 2] =
- * (s_hi, s_lo), each 2^ceil(log2(amax / 448)) of what it scales, so that x ~ s_hi hi + s_lo lo.  pgv_gemv_fp8_a8 then computes
- * y = (W8 x hi) s_hi + (W8 x lo) s_lo with v_mfma_f32_16x16x32_fp8_fp8, times the weights' row scales; modes 0, 2, 3 of pgv_gemv; B <= 16.
- * There is no reference counterpart (the reference has no quantised path); oracle/a8_study.py holds the accuracy study. */
-int pgv_quantize_act_hilo(pgv_ctx *ctx, int dtype, const void *d_x, int ldx, int B, int K, void *d_x8, float *d_xscales, void *stream);
-int pgv_gemv_fp8_a8(pgv_ctx *ctx, int dtype, int mode, const void *d_W8, const float *d_wscales, const void *d_x8, const float *d_xscales,
-                    void *d_out, int ldo, int N, int K, int B, void *stream);
 int pgv_layernorm(pgv_ctx *ctx, int dtype, const float *d_x, const float *d_gamma, const float *d_beta, float eps,
                   void *d_y, int rows, int cols, void *stream);
 int pgv_rmsnorm(pgv_ctx *ctx, int dtype, const float *d_x, const float *d_gamma, float eps, void *d_y, int rows, int cols,

@@ -18,6 +18,7 @@ count and ISA; the GPU test recomputes the figure from the stored logits against
 
 Usage: python oracle/gen_yardstick.py [7b_fp16 7b_bf16 13b_fp8_fp16 13b_fp8_bf16]   (13B: ~50 GB of host memory)
        python oracle/gen_yardstick.py vit                                            (HF CLIPVisionModel fp16 / bf16, 8 frames)
+       python oracle/gen_yardstick.py tf [7b_bf16 13b_fp8_bf16]                      (the reference's own teacher-forced argmax agreement)
 """
 from __future__ import annotations
 
@@ -55,7 +56,8 @@ def case_weights(name: str, dtype: str, fp8: bool) -> dict:
     return w
 
 
-def reference_logits(cfg: synth.LlamaCfg, w: dict, ids, feats, tdt) -> torch.Tensor:
+def reference_logits(cfg: synth.LlamaCfg, w: dict, ids, feats, tdt, first: int | None = None) -> torch.Tensor:
+    """Logits of the reference's own forward in `tdt`: the last position [vocab], or (first given) positions first.. [S - first, vocab]."""
     from transformers import CLIPVisionConfig
     import transformers.modeling_utils as mu
     from video_chatgpt.model.video_chatgpt import VideoChatGPTConfig, VideoChatGPTLlamaForCausalLM
@@ -90,12 +92,54 @@ def reference_logits(cfg: synth.LlamaCfg, w: dict, ids, feats, tdt) -> torch.Ten
     vc.vid_patch_token, vc.vid_start_token, vc.vid_end_token, vc.use_vid_start_end = cfg.vocab - 3, cfg.vocab - 2, cfg.vocab - 1, True
     with torch.no_grad():
         o = model(input_ids=torch.tensor([ids]), video_spatio_temporal_features=feats.to(tdt)[None], use_cache=False)
-    return o.logits[0, -1].float()
+    return o.logits[0, -1].float() if first is None else o.logits[0, first:].float()
+
+
+def teacher_forced_yardstick(names):
+    """`tf` mode: the reference's OWN teacher-forced argmax agreement in 16 bits.  The seeded continuation of
+    tests/test_gpu_fulldepth.py (fd.teacher_tokens, fd.N_TEACHER positions) goes through the reference's forward in the case's dtype in one
+    causal pass; stored per case: the reference's argmax at every visited position (`<case>_tf_ref_argmax`), the fp32 oracle's argmax and
+    top-1/top-2 margin there, and the agreement count.  The GPU test recounts the agreement against its own oracle run and requires the HIP
+    path's unfiltered count to be at least the reference's."""
+    gg._import_reference()
+    out = dict(np.load(OUT)) if os.path.exists(OUT) else {}
+    for name in names:
+        case, dtype, fp8 = CASES[name]
+        tdt = torch.float16 if dtype == "float16" else torch.bfloat16
+        c = fd.CASES[case]
+        cfg = c["cfg"]
+        t0 = time.time()
+        w = case_weights(case, dtype, fp8)
+        ids, feats = fd.make_prompt(cfg, c["prompt_seed"])
+        cont = fd.teacher_tokens(cfg, c["prompt_seed"], fd.N_TEACHER[case])
+        print(f"[{name}] weights {time.time() - t0:.0f}s", flush=True)
+        t0 = time.time()
+        lg_truth, margins, arg_truth = fd.teacher_forced_reference(w, cfg, ids, feats, cont)
+        print(f"[{name}] fp32 oracle, one causal pass over {len(ids) + len(cont)} tokens: {time.time() - t0:.0f}s", flush=True)
+        t0 = time.time()
+        ref = reference_logits(cfg, w, list(ids) + list(cont), feats, tdt, first=len(ids) - 1)
+        print(f"[{name}] reference forward in {dtype}: {time.time() - t0:.0f}s", flush=True)
+        arg_ref = ref.argmax(-1)
+        agree = int((arg_ref == torch.tensor(arg_truth)).sum())
+        errs = ((ref.double() - lg_truth.double()).norm(dim=-1) / lg_truth.double().norm(dim=-1))
+        print(f"[{name}] reference {dtype} teacher-forced: argmax agrees at {agree}/{len(arg_truth)} positions; normwise error "
+              f"first {float(errs[0]):.3e} worst {float(errs.max()):.3e}", flush=True)
+        out[f"{name}_tf_ref_argmax"] = arg_ref.numpy().astype(np.int32)
+        out[f"{name}_tf_truth_argmax"] = np.asarray(arg_truth, dtype=np.int32)
+        out[f"{name}_tf_truth_margin"] = np.asarray(margins, dtype=np.float32)
+        out[f"{name}_tf_agree"] = np.int64(agree)
+        out[f"{name}_tf_ref_err_worst"] = np.float64(float(errs.max()))
+        del w, ref, lg_truth
+        gc.collect()
+    np.savez_compressed(OUT, **out)
+    print("wrote", OUT, {k: int(v) for k, v in out.items() if k.endswith("_tf_agree")})
 
 
 def main():
     if sys.argv[1:] == ["vit"]:
         return vit_yardstick()
+    if sys.argv[1:2] == ["tf"]:
+        return teacher_forced_yardstick(sys.argv[2:] or ["7b_bf16", "13b_fp8_bf16"])
     names = sys.argv[1:] or ["7b_fp16", "7b_bf16"]
     gg._import_reference()
     out = dict(np.load(OUT)) if os.path.exists(OUT) else {}

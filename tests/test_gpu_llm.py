@@ -602,15 +602,21 @@ print("unfolded ok")
 
 def test_13b_fp8_down_proj_8_phase_form_is_bitwise_the_16_row_kernel(ctx):
     """Config 5's down_proj (fp8, K = 13 824, 320 row blocks) runs the 8-phase residual producer also at batches <= 16
-    (llm_kernels.hip: w8 && K >= PGV_GEMV_K8_NARROW_MINK, default 12 288).  The form is a different launch shape of the same
-    arithmetic: prefill + 4 decode steps of a 13B-shaped 2-layer fp8 model at 1, 3 and 16 sequences must give the same logits BIT FOR BIT
-    with the threshold out of reach (the 16-row kernel) -- the switch is read once per process, so each setting runs in a child."""
+    (gemv.hip choose_gemv: w8 && K >= 12 288).  The form is a different launch shape of the same arithmetic: prefill + 4 decode steps of a
+    13B-shaped 2-layer fp8 model at 1, 3 and 16 sequences must give the same logits BIT FOR BIT with the threshold out of reach (the 16-row
+    kernel).  The threshold is a launch-shape switch of the LAB library only (-DPGV_LAB: PGV_GEMV_K8_NARROW_MINK; the release library reads no
+    launch-shape switches), so both settings run in children bound to libpgv_lab.so -- the same sources, built here if missing -- and the
+    release library (this process) must reproduce the same digest."""
     import hashlib
     import subprocess
     import sys
+    from video_llava_amd import build as pgv_build
+    lab_lib = pgv_build.build(lab=True)
     code = f'''
 import sys, os, hashlib, numpy as np, torch
 sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r}); sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r})
+from video_llava_amd import _lib
+if os.environ.get("PGV_TEST_LAB_LIB"): _lib.LIB_PATH = os.environ["PGV_TEST_LAB_LIB"]
 from oracle import synth
 from helpers import make_model
 cfg = synth.LlamaCfg(layers=2, hidden=5120, inter=13824, heads=40)
@@ -636,129 +642,8 @@ for B in (1, 3, 16):
 print("DIGEST", h.hexdigest())
 '''
     digests = []
-    for mink in ("12288", "100000000"):
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, PGV_GEMV_K8_NARROW_MINK=mink))
+    for env in (dict(PGV_TEST_LAB_LIB=lab_lib, PGV_GEMV_K8_NARROW_MINK="12288"), dict(PGV_TEST_LAB_LIB=lab_lib, PGV_GEMV_K8_NARROW_MINK="100000000"), {}):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
         assert r.returncode == 0 and "DIGEST" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
         digests.append(r.stdout.split("DIGEST")[1].split()[0])
-    assert digests[0] == digests[1], digests
-
-
-# --------------------------------------------------------------------------------------------------
-# fp8 x fp8 MFMA form of the decode GEMV (BASELINE configs[4] "fp8 MFMA weight path"; flag PGV_FP8_MFMA=1): activation = hi + lo e4m3
-# --------------------------------------------------------------------------------------------------
-def _hilo_image(ctx, x, dtype):
-    from video_llava_amd import _lib
-    B, K = x.shape
-    x8 = torch.zeros(B * K * 2, dtype=torch.uint8, device=DEV)
-    xs = torch.zeros(B, 2, dtype=torch.float32, device=DEV)
-    _lib.check(ctx.lib.pgv_quantize_act_hilo(ctx.handle, _lib.dtype_code(dtype), x.data_ptr(), K, B, K, x8.data_ptr(), xs.data_ptr(), _lib.stream_ptr()))
-    codes = x8.view(B, K // 8, 2, 8)
-    hi = codes[:, :, 0].reshape(B, K).view(torch.float8_e4m3fn).float() * xs[:, :1]
-    lo = codes[:, :, 1].reshape(B, K).view(torch.float8_e4m3fn).float() * xs[:, 1:]
-    return x8, xs, hi, lo
-
-
-@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("B,K", [(1, 512), (5, 4096), (16, 11008), (3, 13824)])
-def test_act_hilo_quantiser_matches_cpu_twin(ctx, dtype, B, K):
-    """pgv_quantize_act_hilo == the CPU twin of oracle/a8_study.py bit for bit: hi = e4m3(x) under the per-token power-of-two scale of the
-    exact amax (ollm.quantize_e4m3_rows, the weight quantiser's rule), lo = e4m3(x - hi) under its own; rows with outliers and an all-zero row."""
-    g = torch.Generator().manual_seed(B * 31 + K)
-    x = torch.randn(B, K, generator=g) * 0.7
-    x[0, 5] = 37.0                                              # an outlier channel sets the first row's scale
-    if B > 2:
-        x[2] = 0.0
-    xd = x.to(dtype).to(DEV)
-    _, xs, hi, lo = _hilo_image(ctx, xd, dtype)
-    xf = xd.float().cpu()
-    hi_t = ollm.quantize_e4m3_rows(xf)
-    lo_t = ollm.quantize_e4m3_rows(xf - hi_t)
-    assert torch.equal(hi.cpu(), hi_t) and torch.equal(lo.cpu(), lo_t)
-    err = (xf - hi_t - lo_t).abs().amax(dim=1) / xf.abs().amax(dim=1).clamp_min(1e-30)
-    assert float(err.max()) < 2 ** -7                           # the pair keeps ~8 bits of every activation relative to the row's amax
-
-
-@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("mode,N,K,B", [(3, 512, 1024, 5), (0, 12288, 4096, 8), (0, 15360, 5120, 16), (2, 22016, 4096, 8), (3, 32003 // 16 * 16, 4096, 3)])
-def test_gemv_fp8_a8_is_the_exact_product_of_the_quantised_operands(ctx, dtype, mode, N, K, B):
-    """pgv_gemv_fp8_a8 (v_mfma_f32_16x16x32_fp8_fp8 on the e4m3 weight codes and the hi / lo activation image) against fp64 arithmetic on the
-    SAME quantised operands: e4m3 x e4m3 products are exact in fp32, so only the MFMA's fp32 accumulation separates the two (measured
-    1.6e-5 normwise at K = 1024; bar 5e-5 -- two orders below what the activation image itself drops); and against the weight-only form it
-    differs by that image error (~2^-8 per element)."""
-    from video_llava_amd import _lib
-    g = torch.Generator().manual_seed(N + K + B + 7)
-    w = (torch.randn(N, K, generator=g) * 0.05).to(dtype).to(DEV)
-    x = torch.randn(B, K, generator=g).to(dtype).to(DEV)
-    dc = _lib.dtype_code(dtype)
-    wb = torch.zeros(N, K, dtype=dtype, device=DEV)
-    _lib.check(ctx.lib.pgv_pack_blocked(ctx.handle, dc, w.data_ptr(), N, K, wb.data_ptr(), _lib.stream_ptr()))
-    w8 = torch.zeros(N * K, dtype=torch.uint8, device=DEV)
-    sc = torch.zeros(N, dtype=torch.float32, device=DEV)
-    _lib.check(ctx.lib.pgv_quantize_fp8_blocked(ctx.handle, dc, wb.data_ptr(), w8.data_ptr(), sc.data_ptr(), N, K, _lib.stream_ptr()))
-    wdq = torch.zeros(N, K, dtype=torch.float32, device=DEV)
-    _lib.check(ctx.lib.pgv_unpack_blocked(ctx.handle, dc, wb.data_ptr(), wdq.data_ptr(), N, K, _lib.stream_ptr()))
-    x8, xs, hi, lo = _hilo_image(ctx, x, dtype)
-
-    def out_buf():
-        return torch.empty(B, N // 2 if mode == 2 else N, dtype=torch.float32 if mode == 3 else dtype, device=DEV)
-    o_a8, o_w8 = out_buf(), out_buf()
-    _lib.check(ctx.lib.pgv_gemv_fp8_a8(ctx.handle, dc, mode, w8.data_ptr(), sc.data_ptr(), x8.data_ptr(), xs.data_ptr(), o_a8.data_ptr(), o_a8.shape[1], N, K, B,
-                                       _lib.stream_ptr()))
-    _lib.check(ctx.lib.pgv_gemv_fp8(ctx.handle, dc, mode, w8.data_ptr(), sc.data_ptr(), x.data_ptr(), K, o_w8.data_ptr(), o_w8.shape[1], N, K, B,
-                                    _lib.stream_ptr()))
-    y = (hi.double() + lo.double()) @ wdq.double().t()
-    if mode == 2:
-        yy = y.view(B, N // 64, 2, 32)
-        y = (torch.nn.functional.silu(yy[:, :, 0]) * yy[:, :, 1]).reshape(B, N // 2)
-    tol16 = 1e-3 if dtype == torch.float16 else 8e-3
-    assert rel(o_a8, y) < (5e-5 if mode == 3 else tol16)
-    assert rel(o_a8, o_w8) < (2 ** -6 if mode == 3 else 2 ** -6 + tol16)
-    if mode == 3:
-        assert rel(o_a8, o_w8) > 1e-6                            # and it IS a different path: the image is not the 16-bit operand
-
-
-def test_fp8_mfma_decode_path_vs_oracle(ctx, golden_dir):
-    """PGV_FP8_MFMA=1 end to end (child process: the switch is read once): a tiny decoder with fp8 weights, fp16 and bf16 activations --
-    every decode GEMV runs as fp8 x fp8 MFMA on the hi / lo activation image.  Against the fp32 oracle on the dequantised weights: logits of
-    prefill + 6 decode steps within the bf16 bar of this model (8e-3: the image keeps about as many bits as bf16 does), greedy tokens equal
-    (oracle margins > 0.25), and the run is NOT bit-identical to the weight-only path (the flag really switches kernels)."""
-    import subprocess
-    import sys
-    code = f'''
-import sys, os, numpy as np, torch
-sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r}); sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r})
-from oracle import synth
-from oracle import llm as ollm
-from helpers import make_model
-cfg = synth.LlamaCfg(**{{**synth.LLAMA_TINY.__dict__, "projector": "linear"}})
-w = synth.make_llama_weights(cfg, seed=78, head_std=0.08)
-V = 104
-rng = np.random.default_rng(5)
-feats = torch.from_numpy(rng.standard_normal((V, 1024)).astype(np.float32) * 0.5)
-ids = [1, 17, 9, cfg.vocab - 2] + [cfg.vocab - 3] * V + [cfg.vocab - 1, 44, 8]
-NEW = 7
-for dtype in (torch.float16, torch.bfloat16):
-    m = make_model(cfg, w, dtype).quantize_weights_fp8()
-    wq = ollm.quantize_llama_weights_fp8(w, round16=dtype)
-    ref, margins, ref_lg = ollm.greedy_generate(wq, cfg, ids, feats, cfg.vocab - 2, cfg.vocab - 1, cfg.vocab - 3, NEW, return_margins=True, return_logits=True)
-    assert min(margins) > 0.25, margins
-    kv, nxt, lg = m.prefill([ids], feats.to(dtype), 192, want_logits=True)
-    got, worst = [int(nxt[0])], 0.0
-    for i in range(NEW):
-        e = float((lg[0].double().cpu() - ref_lg[i].double()).norm() / ref_lg[i].double().norm())
-        worst = max(worst, e)
-        if i + 1 < NEW:
-            nxt, lg = m.decode_step(kv, nxt, want_logits=True)
-            got.append(int(nxt[0]))
-    print(dtype, "worst logits rel err", worst, flush=True)
-    assert worst < 8e-3, worst
-    assert got == ref, (got, ref)
-    print("LOGITS", dtype, float(lg[0].double().abs().sum()), flush=True)
-print("a8 ok")
-'''
-    outs = {}
-    for flag in ("1", "0"):
-        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, PGV_FP8_MFMA=flag))
-        assert r.returncode == 0 and "a8 ok" in r.stdout, (flag, r.stdout[-2000:], r.stderr[-3000:])
-        outs[flag] = [ln for ln in r.stdout.splitlines() if ln.startswith("LOGITS")]
-    assert outs["1"] != outs["0"], "PGV_FP8_MFMA=1 produced the weight-only path's logits bit for bit: the flag did not switch kernels"
+    assert digests[0] == digests[1] == digests[2], digests

@@ -31,6 +31,18 @@ def test_library_builds_and_exports_every_header_symbol():
     assert lib.pgv_version() == _lib.ABI_VERSION
 
 
+def test_release_library_reads_five_switches_and_the_split_merge_lowers_to_sc1():
+    """VERDICT r4 item 8 / ADVICE r4: the release libpgv.so reads exactly the five documented environment switches -- every
+    launch-shape A/B switch lives behind -DPGV_LAB in libpgv_lab.so -- and the fence-free cross-workgroup merge of the split decode attention
+    still lowers to sc1 stores / loads with no cache maintenance (build.check_isa)."""
+    from video_llava_amd import build
+    data = open(build.build(), "rb").read()
+    names = set(re.findall(rb"\x00(PGV_[A-Z0-9_]{3,})\x00", data))        # NUL-delimited C strings: getenv names (PGV_F16 ... inside messages are not)
+    assert names == {b"PGV_DATTN_SPLIT", b"PGV_LLM_NORM_FOLD", b"PGV_NO_GRAPH", b"PGV_VIT_LANES", b"PGV_VIT_LN_FOLD"}, names
+    found = build.check_isa()
+    assert len(found) == 6 and all(v["cache_maintenance"] == 0 and v["atomics"] == 1 for v in found.values())
+
+
 def test_product_path_fails_loudly_without_gpu():
     from video_llava_amd import _lib
     if torch.cuda.is_available():
@@ -137,7 +149,7 @@ def infer(group):
     if 3 in group: raise RuntimeError("bad clip")
     toks = torch.stack([torch.arange(NEW, dtype=torch.int32) + 100 * i for i in group])
     return toks, [NEW - (i % 3) for i in group]
-ans = parallel.run_sharded(N, infer, NEW, rank, world, torch.device("cpu"), per_gpu_batch=1)
+ans = parallel.run_sharded(N, infer, NEW, rank, world, torch.device("cpu"), per_gpu_batch=1, spill_path={str(tmp_path / "preds")!r})
 open({str(tmp_path)!r} + f"/result_{{rank}}.json", "w").write(json.dumps(ans))   # files, not stdout: rank lines interleave
 torch.distributed.destroy_process_group()
 ''')
@@ -152,6 +164,7 @@ torch.distributed.destroy_process_group()
     want = [[100 * i + t for t in range(6 - (i % 3))] for i in range(5)]
     want[3] = []                                                        # failed clip keeps an empty slot
     assert ans == want
+    assert not list(tmp_path.glob("preds.rank*.partial.json"))          # the rank-local spill files are removed once the all-gather succeeded
 
 
 def _spawn_ranks(script, world, extra_env=None, timeout=180):
@@ -217,7 +230,7 @@ def infer(group):
     return torch.zeros(len(group), 3, dtype=torch.int32), [3] * len(group)
 t0 = time.time()
 try:
-    parallel.run_sharded(4, infer, 3, rank, world, torch.device("cpu"), per_gpu_batch=2)
+    parallel.run_sharded(4, infer, 3, rank, world, torch.device("cpu"), per_gpu_batch=2, spill_path={str(tmp_path / "preds")!r})
 except parallel.CollationError as e:
     print("LOUD after %.1f s:" % (time.time() - t0), e); sys.exit(5)
 print("collated?!"); sys.exit(0)
@@ -227,6 +240,9 @@ print("collated?!"); sys.exit(0)
     assert outs[1][0] == 7
     assert outs[0][0] == 5 and "LOUD" in outs[0][1] and "HUNG" not in outs[0][1], outs[0]
     assert time.time() - t0 < 120
+    # the survivor's finished shard is not lost with the collation -- its rank-local file holds it and the error names it
+    kept = json.load(open(tmp_path / "preds.rank0.partial.json"))
+    assert kept["indices"] == [0, 1] and kept["tokens"] == [[0, 0, 0], [0, 0, 0]] and kept["lengths"] == [3, 3] and "preds.rank0.partial.json" in outs[0][1]
 
 
 def test_rank_affinity_slices_and_silent_fallback():
@@ -243,6 +259,47 @@ def test_rank_affinity_slices_and_silent_fallback():
     before = os.sched_getaffinity(0)
     assert parallel.pin_rank_to_numa_node(0, 1) is None                          # no GPU in the build container
     assert os.sched_getaffinity(0) == before
+
+
+def test_rank_affinity_from_gpu_position_in_sysfs(tmp_path):
+    """the core slice comes from the GPU's position among ALL GPUs of its NUMA node in sysfs, not from the per-job rank order -- two
+    jobs on one host (each seeing 4 of 8 GPUs) pin disjoint slices that together cover each node.  Fake sysfs: 8 GPUs, 4 per node, plus a
+    non-GPU PCI function and another vendor's display controller that must be ignored; the CPU lists are cut to the cores this process may use."""
+    from video_llava_amd import parallel
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) < 8:
+        pytest.skip("needs 8 usable cores")
+    half = len(allowed) // 2
+    node_cpus = [allowed[:half], allowed[half:]]
+    root = tmp_path / "sys"
+    bdfs = [f"0000:{0x10 + 0x10 * i:02x}:00.0" for i in range(8)]
+    def dev(bdf, vendor, cls, node):
+        d = root / "bus" / "pci" / "devices" / bdf
+        d.mkdir(parents=True)
+        (d / "vendor").write_text(vendor + "\n"); (d / "class").write_text(cls + "\n"); (d / "numa_node").write_text(f"{node}\n")
+    for i, b in enumerate(bdfs):
+        dev(b, "0x1002", "0x120000", i // 4)
+    dev("0000:05:00.0", "0x8086", "0x030000", 0)                                 # another vendor's display controller
+    dev("0000:10:00.1", "0x1002", "0x040300", 0)                                 # audio function of a GPU
+    for n in (0, 1):
+        d = root / "devices" / "system" / "node" / f"node{n}"
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(",".join(str(c) for c in node_cpus[n]) + "\n")
+    assert parallel.node_gpu_bdfs(0, str(root)) == bdfs[:4] and parallel.node_gpu_bdfs(1, str(root)) == bdfs[4:]
+    before = os.sched_getaffinity(0)
+    try:
+        got = {}
+        for job, visible in (("A", [0, 2, 4, 6]), ("B", [1, 3, 5, 7])):              # two jobs, interleaved GPUs; local rank k of BOTH jobs used to get slice k
+            for local, g in enumerate(visible):
+                os.sched_setaffinity(0, before)
+                share = parallel.pin_rank_to_numa_node(local, sysfs_root=str(root), bdf=bdfs[g], quiet=True)
+                assert share and os.sched_getaffinity(0) == set(share)
+                got[g] = share
+        for n in (0, 1):
+            parts = [got[g] for g in range(4 * n, 4 * n + 4)]
+            assert sorted(sum(parts, [])) == node_cpus[n], (n, parts)               # disjoint and covering, across the two jobs
+    finally:
+        os.sched_setaffinity(0, before)
 
 
 @pytest.mark.parametrize("launcher", ["self", "torchrun"])

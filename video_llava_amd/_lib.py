@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpgv.so")
 
-ABI_VERSION = 210          # PGV_VERSION of include/pgv.h this table was written against
+ABI_VERSION = 300          # PGV_VERSION of include/pgv.h this table was written against
 PGV_OK, PGV_EINVAL, PGV_EHIP, PGV_ENOMEM, PGV_ESTATE, PGV_ENAME = 0, 1, 2, 3, 4, 5
 PGV_F16, PGV_BF16, PGV_F32 = 0, 1, 2
 EPI_NONE, EPI_BIAS, EPI_BIAS_QGELU, EPI_BIAS_GELU, EPI_RESID, EPI_BIAS_RESID, EPI_SWIGLU, EPI_F32 = range(8)
@@ -77,8 +77,6 @@ PROTOTYPES = {
     "pgv_unpack_blocked": (_i, [_vp, _i, _vp, _vp, _i, _i, _vp]),
     "pgv_quantize_fp8_blocked": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "pgv_gemv_fp8": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
-    "pgv_quantize_act_hilo": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),
-    "pgv_gemv_fp8_a8": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "pgv_llm_quantize_fp8": (_i, [_vp, _vp, _vp]),
     "pgv_llm_is_fp8": (_i, [_vp]),
     "pgv_llm_get_weight": (_i, [_vp, _vp, C.c_char_p, _vp, _vp]),

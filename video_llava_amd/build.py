@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libpgv.so")
-SOURCES = ["api.hip", "gemm.hip", "elementwise.hip", "vit_attn.hip", "weights.hip", "fp8.hip", "vit.hip", "llm_kernels.hip", "llm.hip"]
+SOURCES = ["api.hip", "gemm.hip", "elementwise.hip", "vit_attn.hip", "weights.hip", "fp8.hip", "vit.hip", "llm_prefill.hip", "gemv.hip", "decode_attn.hip", "sampling.hip", "llm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-ffp-contract=fast"]
 # Attention kernels run VALU softmax on the MFMA results every chunk: keep their accumulators in the VGPR file (hipcc otherwise puts
@@ -130,5 +130,40 @@ def build(force: bool = False, verbose: bool = False, lab: bool = False) -> str:
     return LIB
 
 
+def check_isa() -> dict:
+    """Build-time check of the one place where the code leans on the gfx950 LOWERING rather than on the HIP memory model: the
+    cross-workgroup merge of decode_attn_split_kernel moves every shared byte with relaxed agent-scope atomics and no fences, which is correct
+    only while those lower to write-through stores / memory-side loads (`sc1`).  Compiles csrc/decode_attn.hip to device assembly and requires,
+    in every instantiation of the kernel: the partial-state and ticket stores and the merge loads carry sc1, there is exactly one ticket
+    atomic, and no cache write-back / invalidate was inserted.  Raises RuntimeError otherwise (a compiler upgrade that changes the lowering
+    fails the build instead of silently reading stale partial states; PGV_DATTN_SPLIT=1 is the run-time fallback).  Returns the counts."""
+    import re
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "decode_attn.s")
+        r = subprocess.run([_hipcc(), *[f for f in FLAGS if f != "-fPIC"], "--cuda-device-only", "-S", os.path.join(CSRC, "decode_attn.hip"), "-o", out],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"check_isa: hipcc -S failed:\n{r.stderr}")
+        text = open(out).read()
+    found = {}
+    for m in re.finditer(r"^(_ZN\S*decode_attn_split_kernelI(\w+?)Li(\d)E\S*):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
+        name, dt, split, body = m.group(1), m.group(2), int(m.group(3)), m.group(4)
+        st = len(re.findall(r"global_store_dword\b.*\bsc1\b", body))
+        ld = len(re.findall(r"global_load_dword\b.*\bsc1\b", body))
+        at = len(re.findall(r"global_atomic_add\b", body))
+        bad = len(re.findall(r"buffer_wbl2|buffer_inv", body))
+        found[(dt, split)] = dict(sc1_stores=st, sc1_loads=ld, atomics=at, cache_maintenance=bad)
+        if st < 4 or ld < 3 * split or at != 1 or bad:
+            raise RuntimeError(f"check_isa: {name}: sc1 stores {st} (need >= 4), sc1 loads {ld} (need >= {3 * split}), ticket atomics {at} (need 1), "
+                               f"cache maintenance instructions {bad} (need 0): the fence-free merge of the split decode attention is not safe with this "
+                               "compiler's lowering -- set PGV_DATTN_SPLIT=1 and fix csrc/decode_attn.hip")
+    if len(found) != 6:
+        raise RuntimeError(f"check_isa: expected 6 instantiations of decode_attn_split_kernel (2 dtypes x splits 2/4/8), found {sorted(found)}")
+    return found
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True, lab="--lab" in sys.argv))
+    if "--check-isa" in sys.argv:
+        print(check_isa())

@@ -2,7 +2,7 @@
 #include <stdarg.h>
 #include <string.h>
 
-#include "pgv_common.h"
+#include "llm_internal.h"
 
 static thread_local char g_err[1024] = "";
 
@@ -36,6 +36,11 @@ extern "C" int pgv_ctx_create(int device, pgv_ctx** out) {
         pgv_set_error("pgv_ctx_create: cannot allocate the zero-bias vector");
         delete c;
         return PGV_ENOMEM;
+    }
+    if (int rc = pgv_gemv_configure(c); rc != PGV_OK) {      // per-device function attributes (gemv.hip), outside any graph capture
+        (void)hipFree(c->zero_bias);
+        delete c;
+        return rc;
     }
     *out = c;
     return PGV_OK;

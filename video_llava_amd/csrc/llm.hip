@@ -5,37 +5,10 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "pgv_common.h"
+#include "llm_internal.h"
 #include "weights.h"
 
-int pgv_launch_rmsnorm(int dtype, const float* x, const float* g, float eps, void* y, int rows, int cols, hipStream_t s);
-int pgv_launch_embed_splice(int dtype, const int* row_src, const void* embed, const void* video, float* resid, int M, int H, hipStream_t s);
-int pgv_launch_gather_rows(const float* src, const int* rows, float* dst, int B, int H, hipStream_t s);
-int pgv_launch_rope_kv_write(int dtype, void* qkv, const int* row_b, const int* row_pos, const void* rope, void* Kc, void* Vc, int M, int H,
-                             int heads, int max_seq, hipStream_t s);
-int pgv_launch_prefill_attn(pgv_ctx* ctx, int dtype, const void* qkv, void* out, const void* Kc, const void* Vc, const int* cu, int B, int max_len,
-                            int H, int heads, int max_seq, double flops, hipStream_t s);
-int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void* x, int ldx, void* out, int ldo, int N, int K, int B, hipStream_t s,
-                    const float* wscale = nullptr, const GemvNorm* norm = nullptr, const float* xscale = nullptr);
-int pgv_launch_quant_hilo(int dtype, const void* x, int ldx, int K, int B, void* x8, float* scales, hipStream_t s);
-int pgv_launch_embed_tok_norm(int dtype, const int* tok, const void* embed, float* resid, const float* gamma, void* xg, float* ssq, int B, int H, hipStream_t s);
-int pgv_launch_quantize_fp8(int dtype, void* w16_blocked, void* w8_blocked, float* scales, long long N, long long K, hipStream_t s);
-int pgv_launch_unpack_blocked(int dtype, const void* src, float* dst, long long N, long long K, long long row_blk, long long blk_stride, long long row_off,
-                              long long rows, hipStream_t s);
-int pgv_launch_final_prep(int dtype, const float* resid, const float* gamma, void* xg, float* ssq, int B, int H, hipStream_t s);
-int pgv_launch_decode_attn(pgv_ctx* ctx, int dtype, const void* qkv, const int* pos, const void* rope, void* Kc, void* Vc, void* out, int B, int H,
-                           int heads, int max_seq, double bytes, hipStream_t s, float* part, unsigned* ticket);
-constexpr int kDattnSplitMax = 8, kDattnPart = 128 + 2;       // llm_kernels.hip: DSPLIT_MAX, DPART
-int pgv_launch_sample(const float* logits, int V, int B, float temperature, int top_k, const float* u, int u_stride, int u_by_step, int* next, int* pos,
-                      int* step, int* hist, int hist_stride, int* done, int eos, int advance, hipStream_t s);
-int pgv_launch_argmax_parts(const float* val, const int* idx, int nblk, int amax_ts, int V, int B, int* next, int* pos, int* step, int* hist, int hist_stride, int* done,
-                            int eos, int advance, hipStream_t s);
-constexpr int kMaxBatch = 64;        // decode GEMVs: up to 4 MFMA column tiles of 16 sequences per weight fragment
-enum { GV_STORE16 = 0, GV_RESID = 1, GV_SWIGLU = 2, GV_F32 = 3, GV_RESIDNORM = 5 };
-enum { AM_INC_POS = 1, AM_RECORD = 2, AM_SAMPLE = 4 };
-
 constexpr int kMaxPos = 4096;   // max_position_embeddings of LLaVA-1.5 / Vicuna-1.5
-constexpr int kHD = 128;
 
 struct LlmLayer {
     float *in_g, *post_g;
@@ -72,10 +45,9 @@ struct pgv_kv {
     // fixed-address decode buffers (so a decode step can be captured into a hipGraph)
     float* resid; void* xn; void* qkv; void* ao; void* act; float* logits;
     float* amax_val; int* amax_idx;     // greedy candidates of the lm_head GEMV, tile-major: [ceil(B / 16)][vocab_cap / 16][16]
-    float* ssq;                         // sum-of-squares partials of the folded RMSNorm, tile-major: [ceil(B / 16)][hidden / 16][16] (see GemvArgs in llm_kernels.hip)
+    float* ssq;                         // sum-of-squares partials of the folded RMSNorm, tile-major: [ceil(B / 16)][hidden / 16][16] (see GemvArgs in gemv.hip)
     int ssq_ts, amax_ts;                // their tile strides in elements: hidden, vocab_cap
-    void* k8_part;                      // 8-phase residual producers (llm_kernels.hip gemv_k8_kernel): phase tiles [hidden / 16][8][column tiles][64] float4
-    void* x8; float* xscale;            // fp8 x fp8 MFMA form (PGV_FP8_MFMA=1): hi / lo e4m3 image of the current GEMV's activation operand [B][max(hidden, inter)] x 2 B, scales [B][2]
+    void* k8_part;                      // 8-phase residual producers (gemv.hip gemv_k8_kernel): phase tiles [hidden / 16][8][column tiles][64] float4
     float* dattn_part; unsigned* dattn_ticket;   // context-split decode attention: partial states [B * heads][8][130], arrival tickets [B * heads] (zero between launches)
     int *d_pos, *d_cur, *d_step, *d_done, *d_hist;
     std::vector<int> h_len;
@@ -307,7 +279,7 @@ extern "C" int pgv_kv_create(pgv_ctx* ctx, pgv_llm* llm, int batch, int max_seq,
     const size_t o_resid = take(B * H * 4), o_xn = take(B * H * 2), o_qkv = take(B * 3 * H * 2), o_ao = take(B * H * 2), o_act = take(B * I * 2),
                  o_logits = take(B * V * 4), o_ssq = take(CTn * H * 4), o_av = take(CTn * V * 4), o_ai = take(CTn * V * 4), o_ints = take((4 * B + B * (size_t)max_seq) * 4),
                  o_u = take(B * (size_t)max_seq * 4), o_dpart = take(B * llm->cfg.heads * (size_t)kDattnSplitMax * kDattnPart * 4), o_dtick = take(B * llm->cfg.heads * 4),
-                 o_x8 = take(B * (I > H ? I : H) * 2), o_xs = take(B * 2 * 4), o_k8 = take((H / 16) * 8 * CTn * 64 * 16);
+                 o_k8 = take((H / 16) * 8 * CTn * 64 * 16);
     hipError_t e = hipMalloc((void**)&kv->blob, off);
     if (e != hipSuccess) { delete kv; pgv_set_error("pgv_kv_create: hipMalloc(%zu MiB): %s", off >> 20, hipGetErrorString(e)); return PGV_ENOMEM; }
     char* b = kv->blob;
@@ -317,7 +289,7 @@ extern "C" int pgv_kv_create(pgv_ctx* ctx, pgv_llm* llm, int batch, int max_seq,
     kv->d_pos = ints; kv->d_cur = ints + B; kv->d_step = ints + 2 * B; kv->d_done = ints + 3 * B; kv->d_hist = ints + 4 * B;
     kv->d_u = (float*)(b + o_u);
     kv->dattn_part = (float*)(b + o_dpart); kv->dattn_ticket = (unsigned*)(b + o_dtick);
-    kv->x8 = b + o_x8; kv->xscale = (float*)(b + o_xs); kv->k8_part = (void*)(b + o_k8);
+    kv->k8_part = (void*)(b + o_k8);
     e = hipMemset(ints, 0, (4 * B + B * (size_t)max_seq) * 4);
     if (e == hipSuccess) e = hipMemset(kv->dattn_ticket, 0, B * llm->cfg.heads * 4);
     if (e == hipSuccess) e = hipMemset(kv->ssq, 0, CTn * H * 4);
@@ -351,24 +323,9 @@ static bool norm_fold_enabled() {
     return v == 1;
 }
 
-// PGV_FP8_MFMA=1 (with fp8 weights, folded norms, at most 16 sequences): the decode GEMVs run as v_mfma_f32_16x16x32_fp8_fp8 on the e4m3 weight
-// codes and a hi + lo e4m3 image of the activation (llm_kernels.hip, A8).  A measured alternative, not the default: the image costs one small
-// launch per GEMV and moves the same bytes as the 16-bit operand, so it buys no bandwidth (LAB.md).
-static bool fp8_mfma_enabled() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("PGV_FP8_MFMA"); v = (e && e[0] == '1') ? 1 : 0; }
-    return v == 1;
-}
-
-// One decode GEMV on the fp8 weights: weight-only form (16-bit x, codes widened in registers) or, under the flag, the fp8 x fp8 form.
-static int gemv8(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int mode, const void* w8, const float* ws, const void* x, int K, void* out, int ldo, int N, int B,
+// One decode GEMV on the fp8 weights (weight-only form: 16-bit x, e4m3 codes widened in registers; gemv.hip).
+static int gemv8(pgv_ctx* ctx, pgv_llm* m, pgv_kv*, int mode, const void* w8, const float* ws, const void* x, int K, void* out, int ldo, int N, int B,
                  hipStream_t s, const GemvNorm* nm) {
-    if (fp8_mfma_enabled() && B <= 16) {
-        pgv_prof_begin(ctx, 6, s);
-        PGV_TRY(pgv_launch_quant_hilo(m->dtype, x, K, K, B, kv->x8, kv->xscale, s));
-        pgv_prof_end(ctx, 6, s, 0.0, 0.0);
-        return pgv_launch_gemv(ctx, m->dtype, mode, w8, kv->x8, K, out, ldo, N, K, B, s, ws, nm, kv->xscale);
-    }
     return pgv_launch_gemv(ctx, m->dtype, mode, w8, x, K, out, ldo, N, K, B, s, ws, nm);
 }
 
@@ -402,6 +359,9 @@ extern "C" int pgv_llm_prefill(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, const int32
     if (pgv_llm_missing(m) != 0) { pgv_set_error("pgv_llm_prefill: %d weight tensors not loaded", pgv_llm_missing(m)); return PGV_ESTATE; }
     hipStream_t s = (hipStream_t)stream;
     const int H = m->cfg.hidden, I = m->cfg.inter, heads = m->cfg.heads, vocab = m->cfg.vocab;
+    // arrival tickets of the context-split decode attention: a launch re-arms its own, but an ABORTED decode launch (device fault, process kill
+    // between launches) would leave one non-zero for the next user of this cache -- every prefill starts from zeros
+    PGV_HIP(hipMemsetAsync(kv->dattn_ticket, 0, (size_t)kv->B * heads * sizeof(unsigned), s));
     int M = 0, max_len = 0;
     for (int b = 0; b < B; ++b) {
         PGV_CHECK(h_seq_lens[b] >= 1 && h_seq_lens[b] <= kv->max_seq, "pgv_llm_prefill: sequence %d has %d tokens (cache holds %d)", b, h_seq_lens[b], kv->max_seq);
@@ -511,7 +471,7 @@ static int decode_enqueue(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int eos, int fla
     if (!norm_fold_enabled()) return decode_enqueue_unfolded(ctx, m, kv, eos, flags, s);
     const int H = m->cfg.hidden, I = m->cfg.inter, heads = m->cfg.heads, B = kv->active, L = m->cfg.layers;
     const int nparts = H / 16;                     // one sum-of-squares partial per 16-row workgroup of a residual producer
-    // RMSNorm has no launch of its own in decode (GemvArgs, llm_kernels.hip): the kernel that completes the residual also writes
+    // RMSNorm has no launch of its own in decode (GemvArgs, gemv.hip): the kernel that completes the residual also writes
     // xg = round16(resid * gamma_next) and sum-of-squares partials; the consumer GEMV scales its accumulators by rstd.
     pgv_prof_begin(ctx, 6, s);
     PGV_TRY(pgv_launch_embed_tok_norm(m->dtype, kv->d_cur, m->embed, kv->resid, L > 0 ? m->layers[0].in_g : m->norm_g, kv->xn, kv->ssq, B, H, s));

@@ -175,7 +175,7 @@ struct GemmArgs {
 enum { PGV_EPI_LN_BIAS = 8, PGV_EPI_LN_BIAS_QGELU = 9, PGV_EPI_BIAS_RESID_LNOUT = 10 };     // internal epilogues (gemm.hip)
 int pgv_launch_gemm(pgv_ctx* ctx, int dtype, const GemmArgs& a, hipStream_t s);
 
-// Folded-RMSNorm arguments of the decode GEMVs (llm_kernels.hip, GemvArgs).  Consumer modes (store16 / swiglu / f32): ssq_in [nparts_in][16]
+// Folded-RMSNorm arguments of the decode GEMVs (gemv.hip, GemvArgs).  Consumer modes (store16 / swiglu / f32): ssq_in [nparts_in][16]
 // + hidden + eps (null ssq_in = plain GEMV).  Producer mode (residual + norm): out = fp32 residual, gamma / xg / ssq_out.
 struct GemvNorm {
     const float* ssq_in = nullptr; int nparts_in = 0; int hidden = 1; float eps = 0.f;

@@ -36,14 +36,16 @@ def add_runtime_arguments(parser):
 
 def setup(args, components=None):
     """-> (rank, world, components).  components = (model, vision_tower, tokenizer, image_processor, video_token_len) may be injected."""
+    import os
     from .. import parallel
+    if components is None and int(os.environ.get("WORLD_SIZE", "1")) > 1 and torch.cuda.is_available():
+        # host placement FIRST: threads the process-group backend starts below inherit the mask (ADVICE r4)
+        parallel.pin_rank_to_numa_node(int(os.environ.get("LOCAL_RANK", "0")))
     rank, world, local = parallel.init_distributed()
     if components is None:
         from .model_utils import initialize_model
         if torch.cuda.is_available():
             torch.cuda.set_device(local)
-        if world > 1:
-            parallel.pin_rank_to_numa_node(local)
         components = initialize_model(args.model_name, args.projection_path)
     if getattr(args, "use_asr", False):
         raise NotImplementedError("--use_asr needs the WhisperX transcript stack, which is outside this package's hot path")
@@ -262,12 +264,17 @@ def answer_tasks(args, tasks, components, load_frames, rank, world):
         return toks, lens
 
     device = vision_tower.device if hasattr(vision_tower, "device") else torch.device("cpu")
+    import os
+    spill = os.path.join(args.output_dir, args.output_name) if getattr(args, "output_dir", None) and getattr(args, "output_name", None) else None
+    if spill:
+        os.makedirs(args.output_dir, exist_ok=True)
     try:
         if args.do_sample:
-            answers = parallel.run_sharded(len(tasks), infer_sampled, args.max_new_tokens, rank, world, device, per_gpu_batch=1, length_offset=1, prepare=prepare)
+            answers = parallel.run_sharded(len(tasks), infer_sampled, args.max_new_tokens, rank, world, device, per_gpu_batch=1, length_offset=1, prepare=prepare,
+                                           spill_path=spill)
         else:
             answers = parallel.run_sharded(len(tasks), infer_batch, args.max_new_tokens, rank, world, device, per_gpu_batch=args.batch,
-                                           length_offset=1, prepare=prepare)
+                                           length_offset=1, prepare=prepare, spill_path=spill)
     finally:
         if tfile:
             tfile.close()

@@ -475,8 +475,8 @@ class VideoChatGPTLlamaForCausalLM(nn.Module):
                     n_gen += 1
                     if stop:
                         break
-                if stops is not None and not stop:
-                    stop = check_stops()
+                if stops is not None:                   # also when the chunk ended with every sequence at EOS: a stop string AHEAD of that EOS still cuts
+                    stop = check_stops() or stop
                 nxt = toks[:, n - 1].contiguous()
         if timings is not None:
             _t2 = _time.perf_counter()

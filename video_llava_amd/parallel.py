@@ -16,7 +16,13 @@ import torch
 import torch.distributed as dist
 
 
-DEFAULT_TIMEOUT_S = 600      # of the rendezvous and of every collective: a rank that died must surface as an error on the others, never as a hang
+# Timeout of the rendezvous and of every collective (PGV_DIST_TIMEOUT_S).  The one collective of the path sits at the END of a shard, so the
+# timeout also bounds the SKEW between ranks (unbalanced shards, a rank retrying clips one by one): two hours, not ten minutes -- a rank that
+# died still surfaces as an error on the others, never as a hang, and finished work is not lost meanwhile because every rank writes its own
+# answers to a rank-local file before collating (run_sharded spill_path).  Backend behaviour on expiry: gloo raises on the waiting ranks
+# (-> CollationError below); with nccl (RCCL) the watchdog thread normally ABORTS the process instead of raising, so the `except` branch of
+# gather_answers is not reached there -- the rank-local files are what survives in both cases.
+DEFAULT_TIMEOUT_S = 7200
 
 
 class CollationError(RuntimeError):
@@ -25,7 +31,7 @@ class CollationError(RuntimeError):
 
 def init_distributed(backend: str | None = None, timeout_s: float | None = None) -> tuple[int, int, int]:
     """(rank, world, local_rank) from the torchrun environment; single process when WORLD_SIZE is unset.  `timeout_s` (default
-    PGV_DIST_TIMEOUT_S or 600) bounds the rendezvous and every collective: the survivors of a dead rank fail loudly within it."""
+    PGV_DIST_TIMEOUT_S or DEFAULT_TIMEOUT_S) bounds the rendezvous and every collective: the survivors of a dead rank fail loudly within it."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -71,37 +77,73 @@ def affinity_slice(node_cpus: Sequence[int], ranks_on_node: int, index: int) -> 
     return list(node_cpus[start:start + base + (1 if index < rem else 0)])
 
 
-def gpu_numa_node(device_index: int):
+def _gpu_bdf(device_index: int):
+    pr = torch.cuda.get_device_properties(device_index)
+    return f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+
+
+def gpu_numa_node(device_index: int, sysfs_root: str = "/sys"):
     """NUMA node of a GPU from sysfs (/sys/bus/pci/devices/<domain:bus:dev.fn>/numa_node); None when unknown (no sysfs entry, -1, no GPU)."""
     try:
-        pr = torch.cuda.get_device_properties(device_index)
-        bdf = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
-        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read().strip())
+        node = int(open(f"{sysfs_root}/bus/pci/devices/{_gpu_bdf(device_index)}/numa_node").read().strip())
         return node if node >= 0 else None
     except Exception:                                            # noqa: BLE001 -- placement is best effort by design
         return None
 
 
-def pin_rank_to_numa_node(local_rank: int, n_local: int | None = None):
-    """Bind this process (all threads started after the call inherit it) to this rank's share of the cores of its GPU's NUMA node.
-    Falls back silently -- returns None and changes nothing -- when the topology cannot be read, the mask would be empty, or
-    PGV_RANK_AFFINITY=0.  Returns the CPU list otherwise."""
+def node_gpu_bdfs(numa_node: int, sysfs_root: str = "/sys") -> List[str]:
+    """PCI addresses of ALL AMD GPUs / accelerators of the host that hang off `numa_node`, sorted -- independent of which of them this job
+    can see (HIP_VISIBLE_DEVICES, a second torchrun job on the same host), so two jobs that share a host derive disjoint core slices from it."""
+    out = []
+    base = f"{sysfs_root}/bus/pci/devices"
+    for bdf in sorted(os.listdir(base)):
+        try:
+            d = f"{base}/{bdf}"
+            if open(f"{d}/vendor").read().strip().lower() != "0x1002":
+                continue
+            cls = open(f"{d}/class").read().strip().lower()
+            if not (cls.startswith("0x03") or cls.startswith("0x12")):      # display controllers / processing accelerators (MI300-class parts)
+                continue
+            if not bdf.endswith(".0") or int(open(f"{d}/numa_node").read().strip()) != numa_node:
+                continue
+            out.append(bdf)
+        except Exception:                                        # noqa: BLE001
+            continue
+    return out
+
+
+_pin_logged = False
+
+
+def pin_rank_to_numa_node(local_rank: int, n_local: int | None = None, sysfs_root: str = "/sys", bdf: str | None = None, quiet: bool = False):
+    """Bind this process (all threads started after the call inherit it -- call it BEFORE init_distributed so the backend's threads do too) to
+    this rank's share of the cores of its GPU's NUMA node.  The share is picked by the GPU's position among ALL GPUs of that node in sysfs
+    (node_gpu_bdfs), not by the per-job rank order: two jobs on one host get disjoint slices.  Logs the chosen mask and the ATen thread
+    count once per process.  Falls back silently -- returns None and changes nothing -- when the topology cannot be read, the mask would be
+    empty, or PGV_RANK_AFFINITY=0.  Returns the CPU list otherwise."""
+    global _pin_logged
     if os.environ.get("PGV_RANK_AFFINITY", "1") == "0" or not hasattr(os, "sched_setaffinity"):
         return None
     try:
-        n_local = n_local or int(os.environ.get("LOCAL_WORLD_SIZE", "0")) or torch.cuda.device_count()
-        nodes = [gpu_numa_node(i) for i in range(n_local)]
-        mine = nodes[local_rank] if local_rank < len(nodes) else None
-        if mine is None:
+        bdf = bdf or _gpu_bdf(local_rank)
+        mine = int(open(f"{sysfs_root}/bus/pci/devices/{bdf}/numa_node").read().strip())
+        if mine < 0:
             return None
         allowed = os.sched_getaffinity(0)
-        cpus = [c for c in _parse_cpulist(open(f"/sys/devices/system/node/node{mine}/cpulist").read()) if c in allowed]
-        peers = [i for i, n in enumerate(nodes) if n == mine]
-        share = affinity_slice(cpus, len(peers), peers.index(local_rank))
+        cpus = [c for c in _parse_cpulist(open(f"{sysfs_root}/devices/system/node/node{mine}/cpulist").read()) if c in allowed]
+        peers = node_gpu_bdfs(mine, sysfs_root)
+        if bdf not in peers:
+            return None
+        share = affinity_slice(cpus, len(peers), peers.index(bdf))
         if not share:
             return None
         os.sched_setaffinity(0, share)
-        torch.set_num_threads(max(1, min(torch.get_num_threads(), len(share), 8)))
+        threads = max(1, min(torch.get_num_threads(), len(share), 8))
+        torch.set_num_threads(threads)
+        if not _pin_logged and not quiet:
+            _pin_logged = True
+            print(f"[pgv] local rank {local_rank}: GPU {bdf} on NUMA node {mine} ({peers.index(bdf) + 1} of {len(peers)} GPUs there) -> CPUs "
+                  f"{share[0]}-{share[-1]} ({len(share)}), {threads} ATen threads (PGV_RANK_AFFINITY=0 disables)", flush=True)
         return share
     except Exception:                                            # noqa: BLE001
         return None
@@ -149,14 +191,22 @@ def gather_answers(tokens: torch.Tensor, lengths: torch.Tensor, n_items: int, ra
     return answers
 
 
+def spill_file(spill_path: str, rank: int) -> str:
+    return f"{spill_path}.rank{rank}.partial.json"
+
+
 def run_sharded(n_items: int, infer_batch: Callable[..., tuple], max_new_tokens: int, rank: int, world: int,
-                device, per_gpu_batch: int = 8, length_offset: int = 0, prepare: Callable[[Sequence[int]], object] | None = None):
+                device, per_gpu_batch: int = 8, length_offset: int = 0, prepare: Callable[[Sequence[int]], object] | None = None,
+                spill_path: str | None = None):
     """Run `infer_batch(indices) -> (tokens [len(indices), <=max_new] int tensor, lengths list)` over this rank's shard in
     groups of `per_gpu_batch`, then collate.  A group that raises keeps its slots with length 0.  `length_offset`: see gather_answers
     (the token count stored for slot j is lengths[j] - length_offset).
     `prepare(indices) -> obj` (optional) is the HOST half of a group (decode / sample the frames, pin them): it runs on a background thread
     ONE GROUP AHEAD of the device half, which then receives its result as `infer_batch(indices, obj)` -- the GPU works on group g while the
-    host reads group g + 1.  An exception inside `prepare` is delivered to the group it belongs to (that group fails, the others go on)."""
+    host reads group g + 1.  An exception inside `prepare` is delivered to the group it belongs to (that group fails, the others go on).
+    `spill_path` (world > 1): before the collective, this rank's finished answers go to `<spill_path>.rank<r>.partial.json` ({"indices",
+    "tokens", "lengths", "length_offset"}), removed again once the all-gather has succeeded -- a peer that died or timed out then costs the
+    collation, not the shard's work."""
     mine = shard_indices(n_items, rank, world)
     cap = shard_capacity(n_items, world)
     tokens = torch.zeros(cap, max_new_tokens, dtype=torch.int32, device=device)
@@ -186,4 +236,23 @@ def run_sharded(n_items: int, infer_batch: Callable[..., tuple], max_new_tokens:
     finally:
         if pool is not None:
             pool.shutdown(wait=True, cancel_futures=True)
-    return gather_answers(tokens, lengths, n_items, rank, world, length_offset)
+    spilled = None
+    if spill_path and world > 1:
+        import json
+        spilled = spill_file(spill_path, rank)
+        lens_h, toks_h = lengths.cpu().tolist(), tokens.cpu()
+        with open(spilled, "w") as f:
+            json.dump({"rank": rank, "world": world, "indices": mine, "length_offset": length_offset, "lengths": lens_h[:len(mine)],
+                       "tokens": [toks_h[j, :max(lens_h[j] - length_offset, 0)].tolist() for j in range(len(mine))]}, f)
+    try:
+        answers = gather_answers(tokens, lengths, n_items, rank, world, length_offset)
+    except CollationError as e:
+        if spilled:
+            raise CollationError(f"{e}  This rank's answers are kept in {spilled}.") from e
+        raise
+    if spilled:
+        try:
+            os.remove(spilled)
+        except OSError:
+            pass
+    return answers
