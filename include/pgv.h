@@ -169,9 +169,13 @@ void pgv_kv_destroy(pgv_kv *kv);
  * d_video [B, V, hidden] = mm_projector output, 16-bit (or NULL); h_vid_pos[b] = index of <vid_start>
  * in sequence b, or -1 for a text-only sample (rows (pos, pos+V] are replaced -- the caller has already
  * validated the placeholder run on the host, raising the reference's ValueErrors).
- * Outputs (either may be NULL): d_logits [B, vocab] fp32, d_next [B] int32 greedy argmax. */
+ * Outputs (any may be NULL): d_logits [B, vocab] fp32, d_next [B] int32 greedy argmax, and -- what
+ * VideoChatGPTLlamaForCausalLM.forward returns (:225-226, `logits = self.lm_head(hidden_states)` over ALL positions) --
+ * d_all_logits [sum of h_seq_lens, ld_all] fp32 with ld_all >= vocab rounded up to a multiple of 16 (row r = token r of the
+ * concatenated batch; columns >= vocab hold the zero spare rows of lm_head). */
 int pgv_llm_prefill(pgv_ctx *ctx, pgv_llm *llm, pgv_kv *kv, const int32_t *h_ids, const int32_t *h_seq_lens, int B,
-                    const void *d_video, int V, const int32_t *h_vid_pos, float *d_logits, int32_t *d_next, void *stream);
+                    const void *d_video, int V, const int32_t *h_vid_pos, float *d_logits, int32_t *d_next, float *d_all_logits,
+                    int ld_all, void *stream);
 
 /* One decode step for all B sequences (the `input_ids.shape[1] == 1` branch, :103): consumes
  * d_last [B] token ids, appends to the KV cache, writes d_logits [B, vocab] and/or d_next [B]. */

@@ -26,6 +26,51 @@ from helpers import make_model as _model  # noqa: E402
 
 
 @pytest.mark.parametrize("tag,proj,image", [("lin", "linear", 224), ("mlp", "mlp2x_gelu", 336)])
+def test_forward_is_callable_like_the_reference(ctx, golden_dir, tag, proj, image):
+    """VERDICT r4 missing #5: `model(input_ids=..., video_spatio_temporal_features=..., use_cache=True)` -- the reference's public forward
+    (video_chatgpt/model/video_chatgpt.py:193-251), the way SURVEY.md 8c drives it as an oracle: prefill returns the logits of ALL positions
+    + past_key_values; single-token calls with that cache continue.  Checked against the fixture the REFERENCE's forward produced
+    (`*_prefill_logits` [S, vocab], `*_step_logits`, `*_tokens`)."""
+    g = np.load(os.path.join(golden_dir, "llama_tiny.npz"))
+    cfg = synth.LlamaCfg(**{**synth.LLAMA_TINY.__dict__, "projector": proj})
+    w = synth.make_llama_weights(cfg, seed=int(g[tag + "_weight_seed"]), head_std=float(g["head_std"]))
+    m = _model(cfg, w, torch.float16, image)
+    ids = g[tag + "_ids"].tolist()
+    feats = torch.from_numpy(g[tag + "_feats"]).half()[None]
+    toks_ref = g[tag + "_tokens"].tolist()
+    out = m(input_ids=torch.tensor([ids]), video_spatio_temporal_features=feats, use_cache=True)
+    ref_all = torch.from_numpy(g[tag + "_prefill_logits"])
+    assert tuple(out.logits.shape) == (1, len(ids), cfg.vocab) and out.logits.dtype == torch.float32
+    assert ref_all.shape[0] == len(ids)
+    assert rel(out.logits[0], ref_all) < 1e-3
+    per_pos = [rel(out.logits[0, i], ref_all[i]) for i in range(len(ids))]
+    assert max(per_pos) < 2e-3, (int(np.argmax(per_pos)), max(per_pos))
+    assert out.past_key_values and out.past_key_values.get_seq_length() == len(ids) and out[0] is out.logits
+    tok = out.logits[:, -1].argmax(-1, keepdim=True)
+    got = [int(tok[0, 0])]
+    for i in range(1, len(toks_ref)):
+        out = m(input_ids=tok, past_key_values=out.past_key_values, video_spatio_temporal_features=feats, use_cache=True)
+        assert tuple(out.logits.shape) == (1, 1, cfg.vocab)
+        assert rel(out.logits[0, 0], g[tag + "_step_logits"][i]) < 1e-3, i
+        tok = out.logits[:, -1].argmax(-1, keepdim=True)
+        got.append(int(tok[0, 0]))
+    assert got == toks_ref and out.past_key_values.get_seq_length() == len(ids) + len(toks_ref) - 1
+    # a two-sequence batch of equal-length prompts equals the single runs position by position (text-only rows too)
+    out2 = m(input_ids=torch.tensor([ids, ids]), video_spatio_temporal_features=torch.cat([feats, feats]))
+    assert tuple(out2.logits.shape) == (2, len(ids), cfg.vocab) and torch.equal(out2.logits[0], out2.logits[1])
+    assert rel(out2.logits[0], ref_all) < 1e-3
+    # what has no counterpart in the eval path fails loudly
+    with pytest.raises(NotImplementedError):
+        m(input_ids=torch.tensor([ids]), labels=torch.tensor([ids]))
+    with pytest.raises(NotImplementedError):
+        m(input_ids=torch.tensor([ids[:3]]), past_key_values=out2.past_key_values)
+    with pytest.raises(RuntimeError, match="stale"):
+        stale = out.past_key_values
+        m.generate(torch.tensor([ids]), video_spatio_temporal_features=feats, max_new_tokens=2, eos_token_id=None)
+        m(input_ids=tok, past_key_values=stale)
+
+
+@pytest.mark.parametrize("tag,proj,image", [("lin", "linear", 224), ("mlp", "mlp2x_gelu", 336)])
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 1e-3), (torch.bfloat16, 8e-3)])
 def test_tiny_llama_golden(ctx, golden_dir, tag, proj, image, dtype, tol):
     g = np.load(os.path.join(golden_dir, "llama_tiny.npz"))

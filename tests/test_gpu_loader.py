@@ -177,3 +177,83 @@ def test_vocab_resize_after_generate_recaptures_decode_graph(ctx, tree):
     nb2, lb2 = b.decode_step(kb, nb, want_logits=True)
     assert la.shape[1] == lcfg.vocab and torch.equal(la, lb) and toks_a == toks_b and torch.equal(la2, lb2)
     assert float(la2[0, 512:].abs().max()) > 0                                  # the grown rows are live
+
+
+def test_bin_shards_with_projector_inside_and_projection_path_override(ctx, tmp_path):
+    """the format `liuhaotian/llava-v1.5-7b/13b` ship in (reference docs/1-CLI_DEMO.md:27-29, loaded by
+    video_chatgpt/eval/model_utils.py:104-105): `pytorch_model-0000{1,2}-of-00002.bin` + `pytorch_model.bin.index.json`, with the LLaVA-1.5
+    projector `model.mm_projector.{0,2}.*` (mlp2x_gelu) INSIDE the base shards, and -- order of eval/model_utils.py:104-127 -- a
+    `--projection_path` file loaded afterwards that overrides it.  The .bin tree must load through `initialize_model` token-equal to the
+    safetensors tree holding the same tensors; with a projection file the file's projector must win; without one the shards' projector is
+    live; a stray key of the upstream layout (`model.vision_tower...`) is tolerated like torch's strict=False."""
+    import dataclasses
+    import json
+    import shutil
+    from safetensors.torch import load_file
+    from oracle import llm as ollm
+    from oracle import vision as ovis
+    from video_llava_amd.eval.model_utils import initialize_model
+    from video_llava_amd.inference import build_prompt, video_features
+    lcfg = dataclasses.replace(synth.LLAMA_TINY, projector="mlp2x_gelu")
+    ccfg = synth.CLIP_TINY                                                         # 56 px: not 224 -> the projector comes from config.mm_projector_type
+    st = ckpt.write_checkpoint_tree(str(tmp_path / "st"), lcfg, ccfg, clip_seed=71, llm_seed=72, head_std=0.08)
+    w = st["weights"]
+    proj_keys = sorted(k for k in w if k.startswith("model.mm_projector."))
+    assert proj_keys == ["model.mm_projector.0.bias", "model.mm_projector.0.weight", "model.mm_projector.2.bias", "model.mm_projector.2.weight"]
+    # a DIFFERENT projector for the base shards (what llava-v1.5 itself carries); the projection file holds the trained one (w)
+    rng = np.random.default_rng(73)
+    p_base = {k: torch.from_numpy((rng.standard_normal(w[k].shape) * 0.02).astype(np.float32)).half() for k in proj_keys}
+    # ---- the .bin tree: same config / tokenizer files, shards re-saved with torch.save, projector + a stray upstream key inside shard 2 ----
+    bin_dir = tmp_path / "bin" / "llm"
+    shutil.copytree(st["llm"], bin_dir)
+    weight_map = {}
+    for i in (1, 2):
+        sd = load_file(str(bin_dir / f"model-0000{i}-of-00002.safetensors"))
+        if i == 2:
+            sd.update(p_base)
+            sd["model.vision_tower.vision_tower.vision_model.embeddings.class_embedding"] = torch.zeros(1024, dtype=torch.float16)
+        name = f"pytorch_model-0000{i}-of-00002.bin"
+        torch.save(sd, bin_dir / name)
+        weight_map.update({k: name for k in sd})
+        os.remove(bin_dir / f"model-0000{i}-of-00002.safetensors")
+    os.remove(bin_dir / "model.safetensors.index.json")
+    (bin_dir / "pytorch_model.bin.index.json").write_text(json.dumps({"metadata": {}, "weight_map": weight_map}))
+    assert not [f for f in os.listdir(bin_dir) if f.endswith(".safetensors")]
+    # projection files: the trainer's (projector + embedding table), and one with ONLY the base projector (to build the safetensors twin of case 1)
+    only_base = tmp_path / "p_base.bin"
+    torch.save(p_base, only_base)
+
+    frames = synth.make_frames(7, ccfg.image, seed=74)
+    V = 100 + ccfg.patches
+
+    def run(llm_dir, projection):
+        model, tower, tok, ip, vtl = initialize_model(str(llm_dir), str(projection) if projection else None)
+        assert vtl == V and type(model.get_model().mm_projector).__name__ != "HipLinear"
+        prompt, _ = build_prompt("what is shown?", "pg-video-llava", vtl, True)
+        ids = tok([prompt]).input_ids[0]
+        feats = video_features(frames, tower, ip)
+        kv, nxt, lg = model.prefill([ids], feats[None], 1024, want_logits=True)
+        out = model.generate(torch.tensor([ids]), video_spatio_temporal_features=feats[None], do_sample=False, max_new_tokens=10, eos_token_id=None)
+        return ids, out[0, len(ids):].tolist(), lg[0].float().cpu(), model
+
+    # case 1: no projection path -> the projector inside the .bin shards is live; twin = safetensors tree + a file with only that projector
+    ids, t_bin, lg_bin, m_bin = run(bin_dir, None)
+    assert torch.equal(m_bin.get_model().mm_projector.state_dict()["0.weight"].cpu().half(), p_base["model.mm_projector.0.weight"])
+    _, t_st, lg_st, _ = run(st["llm"], only_base)
+    assert t_bin == t_st and torch.equal(lg_bin, lg_st)
+    # case 2: --projection_path after the shards -> the file's projector (and embedding table) override the shards'
+    _, t_bin2, lg_bin2, m_bin2 = run(bin_dir, st["projector"])
+    _, t_st2, lg_st2, _ = run(st["llm"], st["projector"])
+    assert t_bin2 == t_st2 and torch.equal(lg_bin2, lg_st2)
+    assert torch.equal(m_bin2.get_model().mm_projector.state_dict()["0.weight"].cpu().half(), torch.from_numpy(w["model.mm_projector.0.weight"]).half())
+    assert not torch.equal(lg_bin2, lg_bin), "the projection file did not override the projector of the base shards"
+    # and the overridden model computes what the fp32 oracle computes with the file's weights (lm_head rows of the 3 added tokens: zero-filled)
+    wo = dict(w)
+    head = wo["lm_head.weight"].copy(); head[ckpt.BASE_VOCAB:] = 0
+    wo["lm_head.weight"] = head
+    pooled = ovis.spatio_temporal_pool_torch(ovis.clip_select_features(ovis.clip_preprocess(frames), st["clip_weights"], ccfg)).float()
+    with torch.no_grad():
+        ref = ollm.LlamaOracle(wo, lcfg).prefill(ids, pooled, lcfg.vocab - 2, lcfg.vocab - 1, lcfg.vocab - 3)[0]
+    rel = float((lg_bin2.double() - ref.double()).norm() / ref.double().norm())
+    print(f".bin shards + projection override: prefill logits vs fp32 oracle {rel:.3e}")
+    assert rel < 3e-3

@@ -386,3 +386,39 @@ def test_runner_feature_cache_and_sampling_collation(ctx, tmp_path):
     torch.manual_seed(1234)
     ref = video_chatgpt_infer(np.load(vd / "v_b.npy"), one[0]["question"], "pg-video-llava", model, tower, tok, ip, V, max_new_tokens=12)
     assert len(got) == 1 and got[0]["pred"] == ref and len(ref.split()) == 12
+
+
+def test_rccl_one_rank_process_group_collates_on_the_device(ctx, tmp_path):
+    """the `nccl` (= RCCL) branch of parallel.init_distributed (`device_id=`) and the device-side
+    `all_gather_into_tensor` of parallel.gather_answers had never executed anywhere (a gpurun box has one GPU, the CPU tests use gloo).
+    A ONE-rank process group is legal: this runs both, for real, on the MI355X -- RCCL initialises, the packed int32 answers are gathered on
+    the device and come back intact.  (What still has not run: the same call with 2+ ranks over xGMI.)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "nccl1.py"
+    script.write_text(f'''
+import sys, json, torch
+sys.path.insert(0, {root!r})
+from video_llava_amd import parallel
+rank, world, local = parallel.init_distributed(timeout_s=120)
+assert (rank, world, local) == (0, 1, 0) and torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl"
+dev = torch.device("cuda", 0)
+N, NEW = 5, 6
+def infer(group):
+    toks = torch.stack([torch.arange(NEW, dtype=torch.int32, device=dev) + 100 * i for i in group])
+    return toks, [NEW - (i % 3) + 1 for i in group]
+ans = parallel.run_sharded(N, infer, NEW, rank, world, dev, per_gpu_batch=2, length_offset=1)
+t = torch.ones(4, device=dev); torch.distributed.all_reduce(t); torch.distributed.barrier()
+print("ANSWERS", json.dumps(ans), float(t.sum()))
+torch.distributed.destroy_process_group()
+''')
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29613", PGV_DIST_FORCE_INIT="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("PGV_DIST_BACKEND", None)
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "ANSWERS" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+    line = r.stdout.split("ANSWERS", 1)[1].strip()
+    ans = json.loads(line[:line.rindex("]") + 1])
+    assert ans == [[100 * i + t for t in range(6 - (i % 3))] for i in range(5)]
+    assert line.endswith("4.0")

@@ -63,7 +63,7 @@ PROTOTYPES = {
     "pgv_kv_create": (_i, [_vp, _vp, _i, _i, C.POINTER(_vp)]),
     "pgv_kv_destroy": (None, [_vp]),
     "pgv_kv_len": (_i, [_vp, _i]),
-    "pgv_llm_prefill": (_i, [_vp, _vp, _vp, _vp, C.POINTER(C.c_int32), _i, _vp, _i, C.POINTER(C.c_int32), _vp, _vp, _vp]),
+    "pgv_llm_prefill": (_i, [_vp, _vp, _vp, _vp, C.POINTER(C.c_int32), _i, _vp, _i, C.POINTER(C.c_int32), _vp, _vp, _vp, _i, _vp]),
     "pgv_llm_decode": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pgv_llm_decode_greedy": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "pgv_llm_sample": (_i, [_vp, _vp, _vp, _f, _i, _vp, _vp, _vp]),

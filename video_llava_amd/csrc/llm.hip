@@ -352,7 +352,7 @@ static int lm_head_and_pick(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int B, int eos
 // prefill
 // ---------------------------------------------------------------------------------------------
 extern "C" int pgv_llm_prefill(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, const int32_t* h_ids, const int32_t* h_seq_lens, int B, const void* d_video,
-                               int Vt, const int32_t* h_vid_pos, float* d_logits, int32_t* d_next, void* stream) {
+                               int Vt, const int32_t* h_vid_pos, float* d_logits, int32_t* d_next, float* d_all_logits, int ld_all, void* stream) {
     PGV_CHECK(ctx && m && kv && h_ids && h_seq_lens, "pgv_llm_prefill: null argument");
     PGV_CHECK(kv->llm == m, "pgv_llm_prefill: kv cache belongs to another model");
     PGV_CHECK(B >= 1 && B <= kv->B, "pgv_llm_prefill: batch %d outside [1,%d]", B, kv->B);
@@ -421,6 +421,15 @@ extern "C" int pgv_llm_prefill(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, const int32
         g = GemmArgs{}; g.A = xn; g.lda = H; g.W = l.wgu; g.ldw = H; g.C = act; g.ldc = I; g.M = M; g.N = 2 * I; g.K = H; g.epi = PGV_EPI_SWIGLU; g.w_blocked = true;
         PGV_TRY(pgv_launch_gemm(ctx, m->dtype, g, s));
         g = GemmArgs{}; g.A = act; g.lda = I; g.W = l.wdown; g.ldw = I; g.C = resid; g.ldc = H; g.M = M; g.N = H; g.K = I; g.epi = PGV_EPI_RESID; g.w_blocked = true;
+        PGV_TRY(pgv_launch_gemm(ctx, m->dtype, g, s));
+    }
+    if (d_all_logits) {
+        // the reference's forward output: final norm + lm_head over ALL positions (video_chatgpt.py:225-226) -- on request only
+        const int n16 = (vocab + 15) & ~15;
+        PGV_CHECK(ld_all >= n16 && ld_all % 4 == 0 && n16 <= m->vocab_cap, "pgv_llm_prefill: ld_all %d must be a multiple of 4 and at least %d", ld_all, n16);
+        PGV_TRY(pgv_launch_rmsnorm(m->dtype, resid, m->norm_g, m->cfg.eps, xn, M, H, s));
+        GemmArgs g{};
+        g.A = xn; g.lda = H; g.W = m->lm_head; g.ldw = H; g.C = d_all_logits; g.ldc = ld_all; g.M = M; g.N = n16; g.K = H; g.epi = PGV_EPI_F32; g.w_blocked = true;
         PGV_TRY(pgv_launch_gemm(ctx, m->dtype, g, s));
     }
     // lm_head only on the last position of every sequence (the reference computes all S positions, video_chatgpt.py:226)

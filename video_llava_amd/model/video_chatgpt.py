@@ -81,6 +81,35 @@ class VideoChatGPTLlamaModel(nn.Module):
                 self.mm_projector = build_vision_projector(config, dtype=dtype, device=device)
 
 
+class PastKeyValues:
+    """What forward() hands back as `past_key_values`: the library's KV-cache handle (the cache lives in HBM inside libpgv; HF's tuple of
+    tensors / DynamicCache has no counterpart).  Truthy once it holds tokens, like the tuple the reference tests at model/video_chatgpt.py:256."""
+
+    def __init__(self, owner, kv, batch: int, seq_len: int):
+        self.owner, self.kv, self.batch, self.seq_len = owner, kv, batch, seq_len
+        self.max_seq = min(int(owner.config.max_position_embeddings), 4096)
+
+    def get_seq_length(self, layer_idx: int = 0) -> int:
+        return self.seq_len
+
+    def __bool__(self):
+        return self.seq_len > 0
+
+    def __len__(self):
+        return self.owner.config.num_hidden_layers
+
+
+class CausalLMOutputWithPast:
+    """`.logits` / `.past_key_values`, also indexable like HF's ModelOutput ([0] = logits, [1] = past_key_values)."""
+
+    def __init__(self, logits, past_key_values):
+        self.logits, self.past_key_values = logits, past_key_values
+        self.loss = self.hidden_states = self.attentions = None
+
+    def __getitem__(self, i):
+        return (self.logits, self.past_key_values)[i]
+
+
 class VideoChatGPTLlamaForCausalLM(nn.Module):
     def __init__(self, config: VideoChatGPTConfig, vision_config: Optional[VisionConfig] = None,
                  torch_dtype: torch.dtype = torch.float16, device=None):
@@ -300,8 +329,9 @@ class VideoChatGPTLlamaForCausalLM(nn.Module):
 
     # ---- low-level steps (used by generate and by the parity tests) -------------------------------------
     def prefill(self, seqs: Sequence[Sequence[int]], video_spatio_temporal_features: Optional[torch.Tensor], max_seq: int,
-                want_logits: bool = False):
-        """Run the prompt(s); returns (kv handle, next-token ids [B] int32 on device, logits [B, vocab] or None)."""
+                want_logits: bool = False, want_all_logits: bool = False):
+        """Run the prompt(s); returns (kv handle, next-token ids [B] int32 on device, logits [B, vocab] or None) -- with want_all_logits a fourth
+        entry: the logits of EVERY position, [sum of lengths, vocab] fp32 (what the reference's forward returns, model/video_chatgpt.py:225-226)."""
         B = len(seqs)
         lens = [len(s) for s in seqs]
         feats = video_spatio_temporal_features
@@ -325,10 +355,15 @@ class VideoChatGPTLlamaForCausalLM(nn.Module):
         h_pos = (C.c_int32 * B)(*vid_pos)
         nxt = torch.empty(B, dtype=torch.int32, device=self.device_)
         logits = torch.empty(B, self.vocab_size, dtype=torch.float32, device=self.device_) if want_logits else None
+        ld_all = (self.vocab_size + 15) // 16 * 16
+        all_logits = torch.empty(int(flat.size), ld_all, dtype=torch.float32, device=self.device_) if want_all_logits else None
         _lib.check(self.ctx.lib.pgv_llm_prefill(self.ctx.handle, self.handle, kv, flat.ctypes.data_as(C.c_void_p), h_lens, B,
                                                 proj.data_ptr() if proj is not None else None, V, h_pos,
                                                 logits.data_ptr() if logits is not None else None, nxt.data_ptr(),
+                                                all_logits.data_ptr() if all_logits is not None else None, ld_all,
                                                 _lib.stream_ptr(self.device_)), "pgv_llm_prefill")
+        if want_all_logits:
+            return kv, nxt, logits, all_logits[:, :self.vocab_size]
         return kv, nxt, logits
 
     def decode_step(self, kv, last: torch.Tensor, want_logits: bool = False):
@@ -364,6 +399,45 @@ class VideoChatGPTLlamaForCausalLM(nn.Module):
         _lib.check(self.ctx.lib.pgv_llm_decode_sample(self.ctx.handle, self.handle, kv, first.data_ptr(), n, eos_id, float(temperature), int(top_k),
                                                       u.data_ptr(), toks.data_ptr(), _lib.stream_ptr(self.device_)), "pgv_llm_decode_sample")
         return toks
+
+    # ---- forward: the reference's own public entry (model/video_chatgpt.py:193-251) --------------------------------
+    @torch.no_grad()
+    def forward(self, input_ids=None, attention_mask=None, past_key_values=None, inputs_embeds=None, labels=None, use_cache=None,
+                output_attentions=None, output_hidden_states=None, video_spatio_temporal_features: Optional[torch.Tensor] = None,
+                return_dict=None, **_unused):
+        """`model(input_ids=ids, video_spatio_temporal_features=f, use_cache=True)` -> object with `.logits` [B, S, vocab] and `.past_key_values`;
+        `model(input_ids=tok [B, 1], past_key_values=out.past_key_values, ...)` -> the next step (`input_ids.shape[1] == 1` skips the splice,
+        :103).  This is the recipe SURVEY.md 8c drives the reference with (prefill + cached single-token steps); `generate()` is the fast path
+        and what the reference's own callers use.  Inference only: `labels`, `inputs_embeds`, attention / hidden-state outputs and a padded
+        `attention_mask` have no counterpart in the eval path and raise; logits are fp32 (HF up-casts them for the loss the same way)."""
+        if labels is not None or inputs_embeds is not None or output_attentions or output_hidden_states:
+            raise NotImplementedError("forward(): labels / inputs_embeds / output_attentions / output_hidden_states belong to the training path, "
+                                      "which is outside this package (SURVEY.md 2 OUT-OF-SCOPE)")
+        if input_ids is None:
+            raise ValueError("You have to specify input_ids")
+        ids = torch.as_tensor(input_ids)
+        if ids.dim() == 1:
+            ids = ids[None]
+        B, S = ids.shape
+        if attention_mask is not None and not bool(torch.as_tensor(attention_mask).to(torch.bool).all()):
+            raise NotImplementedError("forward(): padded batches are not supported; pass equal-length prompts or use generate() with a list of prompts")
+        if past_key_values is None:
+            max_seq = min(int(self.config.max_position_embeddings), 4096)
+            if S > max_seq:
+                raise ValueError(f"prompt of {S} tokens exceeds max_position_embeddings {max_seq}")
+            kv, _nxt, _lg, all_lg = self.prefill([row.tolist() for row in ids.cpu()], video_spatio_temporal_features, max_seq, want_all_logits=True)
+            return CausalLMOutputWithPast(all_lg.reshape(B, S, -1), PastKeyValues(self, kv, B, S))
+        if not isinstance(past_key_values, PastKeyValues) or past_key_values.owner is not self:
+            raise ValueError("past_key_values must be the object a previous forward() of this model returned")
+        if S != 1:
+            raise NotImplementedError("forward() with a cache consumes one token per sequence (the reference's decode step, input_ids.shape[1] == 1)")
+        if past_key_values.batch != B:
+            raise ValueError(f"{B} sequences for a cache of {past_key_values.batch}")
+        if self._kv.get((past_key_values.batch, past_key_values.max_seq)) is not past_key_values.kv:
+            raise RuntimeError("past_key_values is stale: the model has run another prefill / generate since (one KV cache is kept alive per model)")
+        _nxt, lg = self.decode_step(past_key_values.kv, ids[:, 0].to(device=self.device_, dtype=torch.int32).contiguous(), want_logits=True)
+        past_key_values.seq_len += 1
+        return CausalLMOutputWithPast(lg[:, None, :], past_key_values)
 
     # ---- generate ---------------------------------------------------------------------------------------
     @torch.no_grad()

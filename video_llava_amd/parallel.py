@@ -35,7 +35,9 @@ def init_distributed(backend: str | None = None, timeout_s: float | None = None)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    # PGV_DIST_FORCE_INIT=1: build the process group also for ONE rank (legal for both backends) -- how the RCCL branch below and the
+    # device-side all-gather of gather_answers are exercised on a 1-GPU box (tests/test_gpu_runners.py)
+    if (world > 1 or os.environ.get("PGV_DIST_FORCE_INIT") == "1") and not dist.is_initialized():
         import datetime
         if backend is None:
             backend = os.environ.get("PGV_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -165,10 +167,10 @@ def gather_answers(tokens: torch.Tensor, lengths: torch.Tensor, n_items: int, ra
     have length -1) -> list of n_items token-id lists in global clip order, identical on every rank.
     length_offset = 1: lengths carry (answer length + 1) and 0 marks a failed clip, which comes back as None -- an empty answer
     (first token EOS) is then distinguishable from a failure.
-    world == 1 short-circuits without touching torch.distributed."""
+    world == 1 without a process group short-circuits without touching torch.distributed."""
     cap, width = tokens.shape
     assert cap == shard_capacity(n_items, world) and lengths.shape == (cap,)
-    if world > 1:
+    if world > 1 or (dist.is_available() and dist.is_initialized()):      # a one-rank process group still takes the collective path
         packed = torch.cat([tokens.reshape(-1), lengths]).contiguous()
         if dist.get_backend() == "gloo":                    # CPU tests and the shared-device bench smoke test: stage through the host
             packed = packed.cpu()
