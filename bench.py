@@ -922,6 +922,9 @@ def main():
         collective, ans_c = time_collective(parallel, toks_c, lens_c, n_global, rank, world, barrier)
         assert all(ans_c[i] == dry_pattern(i, NEW, vocab) for i in range(n_global)), f"rank {rank}: collation mismatch"
         collective["rank_ms_per_step"] = rank_ms
+        free_b, total_b = torch.cuda.mem_get_info(dev)    # device-wide (every process on it): with PGV_BENCH_SHARE_DEVICE=1 the footprint of all N replicas
+        collective["device_mem_used_gb"] = round((total_b - free_b) / 2 ** 30, 1)
+        collective["shared_device"] = bool(os.environ.get("PGV_BENCH_SHARE_DEVICE"))
         collective["rank_ms_per_step_min_max"] = [min(rank_ms), max(rank_ms)]
 
     # ---- profiled pass: hipEvent pairs around every launch of each kernel family, on the launch stream -----------------
