@@ -744,7 +744,19 @@ class Workload:
         roofline["event_calibration"] = cal
         roofline["share_of_step"] = d["ms_per_step_est"] / ms_per_step
         roofline["algorithmic_bytes_per_launch"] = raw[dom]["bytes"] / raw[dom]["launches"] if raw[dom]["bytes"] > 0 else None
-        roofline.update(pmc_traffic(dom, "traffic" if (a.llm == "7b" and a.weights == "16bit" and a.image == 224) else f"{a.llm}_{a.weights}"))
+        tag = "traffic" if (a.llm == "7b" and a.weights == "16bit" and a.image == 224) else (f"{a.llm}_{a.weights}" if a.image == 224 else f"image{a.image}")
+        roofline.update(pmc_traffic(dom, tag))
+        # The MFMA-bound family the north star's 40 % target is about (every nn.Linear of the CLIP tower, the projector and the prefill on the
+        # persistent GEMM) gets its own record next to the dominant (HBM-bound) one: same live event pairs, same PMC cross-check.
+        self.roofline_mfma = None
+        if "gemm" in fam and dom != "gemm":
+            g = fam["gemm"]
+            self.roofline_mfma = {"kernel": "gemm", "bound": "mfma", "achieved": g["tflops"], "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": g["tflops"] / PEAK_MFMA_TFLOPS, "avg_launch_us": g["avg_us"], "launches_per_step": g["launches_per_step"],
+                                  "share_of_step": g["ms_per_step_est"] / ms_per_step,
+                                  "algorithmic_flops_per_launch": raw["gemm"]["flops"] / raw["gemm"]["launches"],
+                                  "algorithmic_bytes_per_launch": raw["gemm"]["bytes"] / raw["gemm"]["launches"]}
+            self.roofline_mfma.update(pmc_traffic("gemm", tag))
         return fam, roofline
 
     def free(self):
@@ -767,12 +779,15 @@ def side_line(args, dev, overrides, steps, warmup, with_roofline=False):
         elapsed, vit_ms, _ = w.timed(steps, warmup)
         ms = elapsed / steps * 1e3
         out = {"value": w.n_global * steps / elapsed, "unit": "videos/sec", "ms_per_step": ms, "steps": steps, "warmup": warmup, "dtype": a.dtype, "llm": a.llm,
-               "llm_weights": a.weights, "clips_per_gpu_per_step": a.clips_per_gpu, "new_tokens": a.new_tokens,
-               "clip_feat_ms_per_step": vit_ms, "clip_feat_frac": w.clip_tflops(vit_ms) / PEAK_MFMA_TFLOPS, "model_build_s": t_build}
+               "llm_weights": a.weights, "image": a.image, "clips_per_gpu_per_step": a.clips_per_gpu, "new_tokens": a.new_tokens,
+               "clip_feat_ms_per_step": vit_ms, "clip_feat_tflops": w.clip_tflops(vit_ms), "clip_feat_frac": w.clip_tflops(vit_ms) / PEAK_MFMA_TFLOPS, "model_build_s": t_build}
         if with_roofline:
             fam, roof = w.profile_pass(ms)
             out["roofline"] = roof
+            if w.roofline_mfma:
+                out["roofline_mfma"] = w.roofline_mfma
             out["family_avg_us"] = {k: v["avg_us"] for k, v in fam.items()}
+            out["family_tflops"] = {k: v["tflops"] for k, v in fam.items() if "tflops" in v}
         return out
     finally:
         w.free()
@@ -965,6 +980,8 @@ def main():
             line["family_share_of_step"] = {k: v["ms_per_step_est"] / ms_per_step for k, v in fam.items()}
         if roofline:
             line["roofline"] = roofline
+            if getattr(wl, "roofline_mfma", None):
+                line["roofline_mfma"] = wl.roofline_mfma
         headline = (args.workload == "full" and args.llm == "7b" and args.weights == "16bit" and args.dtype == "bf16" and S == 224 and world == 1)
         if headline and not args.no_side:
             # Guarded side lines: driver-timed numbers for the parity-grade dtype and for BASELINE configs[4]; a failure costs
@@ -974,7 +991,10 @@ def main():
             side = {}
             for key, ov, st, wu, roof in (("fp16", {"dtype": "fp16"}, 5, 1, False),
                                           ("cfg5_13b_fp8", {"llm": "13b", "weights": "fp8"}, 3, 1, True),
-                                          ("clips32", {"clips_per_gpu": 32}, 2, 1, False)):     # what a long runner queue would use: the weight stream of a token step shared by 32 clips
+                                          # the PRODUCTION configuration of the released PG-Video-LLaVA weights (reference docs/1-CLI_DEMO.md:27-44): ViT-L/14-336
+                                          # (577 tokens per frame), mlp2x_gelu projector, 676 video tokens -- with its own rooflines
+                                          ("image336", {"image": 336}, 3, 1, True),
+                                          ("clips32", {"clips_per_gpu": 32}, 1, 1, False)):     # what a long runner queue would use: the weight stream of a token step shared by 32 clips
                 try:
                     side[key] = side_line(args, dev, ov, st, wu, roof)
                 except Exception as e:                           # noqa: BLE001

@@ -37,7 +37,8 @@ extern "C" int pgv_ctx_create(int device, pgv_ctx** out) {
         delete c;
         return PGV_ENOMEM;
     }
-    if (int rc = pgv_gemv_configure(c); rc != PGV_OK) {      // per-device function attributes (gemv.hip), outside any graph capture
+    int rc_cfg = pgv_vit_attn_configure(c);
+    if (int rc = rc_cfg != PGV_OK ? rc_cfg : pgv_gemv_configure(c); rc != PGV_OK) {      // per-device function attributes (vit_attn.hip, gemv.hip), outside any graph capture
         (void)hipFree(c->zero_bias);
         delete c;
         return rc;

@@ -355,13 +355,68 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
 // its waves 0..7) and runs the same epilogue: BITWISE the 16-row kernel's result, so a sequence is still independent of its batch.
 // NWB row blocks (= waves) per workgroup: 8.
 // ---------------------------------------------------------------------------------------------
-template <typename T, bool W8, int CT, int NWB>
-__global__ __launch_bounds__(NWB * 64) void gemv_k8_kernel(GemvArgs p, f32x4_t* __restrict__ part) {
+// Sum of the eight phase tiles of row block rb in phase order + the epilogue of gemv_mfma_kernel<GV_RESIDNORM>, statement for statement (one wave).
+// MEMSIDE: the tiles were written by OTHER workgroups of the same launch (fused form below): read them with agent-scope relaxed atomic loads
+// (sc1: from the memory side, coherent across the XCDs) instead of plain loads.
+template <typename T, bool W8, int CT, bool MEMSIDE>
+__device__ __forceinline__ void k8_finish_row_block(const GemvArgs& p, const f32x4_t* __restrict__ part, int rb, int lane, const f32x4_t (&r_old)[CT], f32x4_t g_nx) {
+    const int l15 = lane & 15, kg = lane >> 4;
+    const int n0 = rb * 16 + kg * 4;
+    const f32x4_t* src = part + ((size_t)rb * 8 * CT) * 64 + lane;
+    auto ld = [&](const f32x4_t* q) -> f32x4_t {
+        if constexpr (MEMSIDE) {
+            const float* f = (const float*)q;
+            f32x4_t v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = __hip_atomic_load(f + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return v;
+        } else return *q;
+    };
+    f32x4_t tile[CT][8];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int ww = 0; ww < 8; ++ww) tile[ct][ww] = ld(src + (ww * CT + ct) * 64);      // all loads in flight before the first add
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        f32x4_t tot = tile[ct][0];
+#pragma unroll
+        for (int ww = 1; ww < 8; ++ww) tot += tile[ct][ww];
+        if constexpr (W8) tot *= *(const f32x4_t*)(p.wscale + rb * 16 + kg * 4);
+        const int b = ct * 16 + l15;
+        float sq = 0.f;
+        if (b < p.B) {
+            f32x4_t* rp = (f32x4_t*)(p.out + ((size_t)b * p.ldo + n0) * 4);
+            const f32x4_t r = r_old[ct] + tot;
+            *rp = r;
+            const f32x4_t g = g_nx;
+            *(u32x2_t*)(p.xg + ((size_t)b * p.ldo + n0) * 2) = pack4<T>(r[0] * g[0], r[1] * g[1], r[2] * g[2], r[3] * g[3]);
+            sq = (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
+        }
+        sq = rows_sum_to_row3(sq);
+        if (kg == 3) p.ssq_out[(size_t)ct * p.ssq_ts + (size_t)rb * 16 + l15] = sq;
+    }
+}
+
+// FUSED (round 5): no finish launch.  Every workgroup publishes its phase tiles with agent-scope relaxed atomic stores (sc1: written through to
+// the memory side), waits for their acknowledgement, and takes a ticket of its row group; the EIGHTH arriver -- whichever phase it is -- runs the
+// finish for the row group's NWB row blocks (one per wave) reading all eight phase tiles back with sc1 loads and adding them in PHASE order:
+// the result is bitwise the finish kernel's, independent of the arrival order.  Same fence-free scheme as decode_attn_split_kernel
+// (decode_attn.hip; lowering checked at build time by build.check_isa).  The ticket is re-armed by the last arriver.
+template <typename T, bool W8, int CT, int NWB, bool FUSED>
+__global__ __launch_bounds__(NWB * 64) void gemv_k8_kernel(GemvArgs p, f32x4_t* __restrict__ part, unsigned* __restrict__ ticket) {
     extern __shared__ __attribute__((aligned(16))) char xs[];    // [groups of this pass][B rows][128 B], 16-B chunks XORed with (row & 7)
+    __shared__ unsigned s_ticket;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kg = lane >> 4;
-    const int j = blockIdx.x & 7, rb = ((int)blockIdx.x >> 3) * NWB + w;
+    // (row group, phase) of this workgroup.  Workgroups are dealt round-robin over the 8 XCDs (id & 7); when the row-group count is a multiple
+    // of 8 the eight phases of a row group are given ids that share an XCD, so their x slices and the fused hand-off stay inside one L2's reach.
+    const int R = (int)gridDim.x >> 3;
+    int j, rg;
+    if ((R & 7) == 0) { const int q = (int)blockIdx.x >> 3; rg = ((int)blockIdx.x & 7) + 8 * (q >> 3); j = q & 7; }
+    else { j = (int)blockIdx.x & 7; rg = (int)blockIdx.x >> 3; }
+    const int rb = rg * NWB + w;
     const int kblocks = p.K >> 5, j_end = (kblocks + 1) >> 1;
     const int gpw = (j_end - j + 7) >> 3;                        // groups of phase j: j, j + 8, ...
     const int Brows = CT * 16;
@@ -436,11 +491,32 @@ __global__ __launch_bounds__(NWB * 64) void gemv_k8_kernel(GemvArgs p, f32x4_t* 
         }
     }
     f32x4_t* dst = part + (((size_t)rb * 8 + j) * CT) * 64 + lane;
+    if constexpr (!FUSED) {
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) dst[ct * 64] = acc[ct];
+        for (int ct = 0; ct < CT; ++ct) dst[ct * 64] = acc[ct];
+    } else {
+        // the finish's own operands (old residual, gamma: L2 hits) are requested by every workgroup before the hand-off, so the last arriver
+        // does not start a fresh round trip for them after the ticket
+        const int n0 = rb * 16 + kg * 4;
+        f32x4_t r_old[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) r_old[ct] = *(const f32x4_t*)(p.out + ((size_t)min(ct * 16 + l15, p.B - 1) * p.ldo + n0) * 4);
+        const f32x4_t g_nx = *(const f32x4_t*)(p.gamma + n0);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) __hip_atomic_store((float*)(dst + ct * 64) + e, acc[ct][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this thread's write-through stores have been acknowledged ...
+        __syncthreads();                                         // ... and so have everyone's in this workgroup
+        if (tid == 0) s_ticket = __hip_atomic_fetch_add(ticket + rg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (s_ticket != 7u) return;                              // not the eighth arriver
+        if (tid == 0) __hip_atomic_store(ticket + rg, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // re-arm (the next launch is ordered by the kernel boundary)
+        k8_finish_row_block<T, W8, CT, true>(p, part, rb, lane, r_old, g_nx);
+    }
 }
 
-// one wave per row block: the eight phase tiles in phase order, then the epilogue of gemv_mfma_kernel<GV_RESIDNORM> statement for statement
+// unfused form: one wave per row block (a second launch)
 template <typename T, bool W8, int CT>
 __global__ __launch_bounds__(64) void gemv_k8_finish_kernel(GemvArgs p, const f32x4_t* __restrict__ part) {
     const int lane = threadIdx.x, l15 = lane & 15, kg = lane >> 4;
@@ -450,26 +526,7 @@ __global__ __launch_bounds__(64) void gemv_k8_finish_kernel(GemvArgs p, const f3
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) r_old[ct] = *(const f32x4_t*)(p.out + ((size_t)min(ct * 16 + l15, p.B - 1) * p.ldo + n0) * 4);
     const f32x4_t g_nx = *(const f32x4_t*)(p.gamma + n0);
-    const f32x4_t* src = part + ((size_t)rb * 8 * CT) * 64 + lane;
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-        f32x4_t tot = src[(0 * CT + ct) * 64];
-#pragma unroll
-        for (int ww = 1; ww < 8; ++ww) tot += src[(ww * CT + ct) * 64];
-        if constexpr (W8) tot *= *(const f32x4_t*)(p.wscale + rb * 16 + kg * 4);
-        const int b = ct * 16 + l15;
-        float sq = 0.f;
-        if (b < p.B) {
-            f32x4_t* rp = (f32x4_t*)(p.out + ((size_t)b * p.ldo + n0) * 4);
-            const f32x4_t r = r_old[ct] + tot;
-            *rp = r;
-            const f32x4_t g = g_nx;
-            *(u32x2_t*)(p.xg + ((size_t)b * p.ldo + n0) * 2) = pack4<T>(r[0] * g[0], r[1] * g[1], r[2] * g[2], r[3] * g[3]);
-            sq = (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
-        }
-        sq = rows_sum_to_row3(sq);
-        if (kg == 3) p.ssq_out[(size_t)ct * p.ssq_ts + (size_t)rb * 16 + l15] = sq;
-    }
+    k8_finish_row_block<T, W8, CT, false>(p, part, rb, lane, r_old, g_nx);
 }
 
 // decode: resid[b] = embed[tok[b]] plus the producer side of the folded RMSNorm (see GemvArgs): xg = round16(resid * gamma of layer 0's
@@ -541,6 +598,8 @@ int pgv_launch_embed_tok_norm(int dtype, const int* tok, const void* embed, floa
 // ---------------------------------------------------------------------------------------------
 // Launch-shape A/B switches exist in the lab library only (-DPGV_LAB, never loaded by the product): PGV_GEMV_TL3, PGV_GEMV_X2, PGV_GEMV_K8,
 // PGV_GEMV_K8_NARROW_MINK.  The release library uses the defaults.
+constexpr int K8_NWB10_DEFAULT = 0, K8_FUSED_DEFAULT = 0, K8_NARROW_MINK_DEFAULT = 12288;      // round-5 experiments: defaults flip once measured
+
 static int lab_switch(const char* name, int dflt) {
 #ifdef PGV_LAB
     const char* e = getenv(name);
@@ -590,43 +649,63 @@ static const GemvShape kGemvShapes[] = {
     gemv_shape<GV_F32, 1, 4>(), gemv_shape<GV_RESIDNORM, 1, 4>(),
 };
 
-// The 8-phase form of a residual producer (gemv_k8_kernel + gemv_k8_finish_kernel) with CT column tiles; `a` is complete except lds_bytes.
-template <bool W8, int CT>
-static int launch_k8(int dtype, GemvArgs a, int grid, void* k8_part, hipStream_t s) {
+// The 8-phase form of a residual producer with CT column tiles and NWB row blocks (= waves) per workgroup; `a` is complete except lds_bytes.
+// nrb = row blocks of the matrix (N / 16, a multiple of NWB): (nrb / NWB) row groups x 8 phases workgroups.
+template <bool W8, int CT, int NWB, bool FUSED>
+static int launch_k8(int dtype, GemvArgs a, int nrb, void* k8_part, unsigned* k8_ticket, hipStream_t s) {
     const int gpw_max = ((a.K / 32 + 1) / 2 + 7) / 8;
     const unsigned budget = 96u * 1024u, per_group = (unsigned)CT * 16u * 128u;
     unsigned lds = (unsigned)gpw_max * per_group;
     if (lds > budget) lds = budget / per_group * per_group;
     a.lds_bytes = lds;
     f32x4_t* part = (f32x4_t*)k8_part;
-    PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gemv_k8_kernel<T, W8, CT, 8>), dim3(grid), dim3(512), lds, s, a, part));
-    PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gemv_k8_finish_kernel<T, W8, CT>), dim3(grid), dim3(64), 0, s, a, (const f32x4_t*)part));
+    const int grid = nrb / NWB * 8;
+    PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gemv_k8_kernel<T, W8, CT, NWB, FUSED>), dim3(grid), dim3(NWB * 64), lds, s, a, part, k8_ticket));
+    if constexpr (!FUSED) PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gemv_k8_finish_kernel<T, W8, CT>), dim3(nrb), dim3(64), 0, s, a, (const f32x4_t*)part));
     return PGV_OK;
 }
-using k8_launch_fn = int (*)(int dtype, GemvArgs a, int grid, void* k8_part, hipStream_t s);
-static const k8_launch_fn kK8[2][3] = {{&launch_k8<false, 1>, &launch_k8<false, 2>, &launch_k8<false, 4>},      // [fp8 weights][column tiles 1 / 2 / 4]
-                                       {&launch_k8<true, 1>, &launch_k8<true, 2>, &launch_k8<true, 4>}};
+using k8_launch_fn = int (*)(int dtype, GemvArgs a, int nrb, void* k8_part, unsigned* k8_ticket, hipStream_t s);
+template <bool W8, int CT>
+struct K8Row { k8_launch_fn fn[2][2] = {{&launch_k8<W8, CT, 8, false>, &launch_k8<W8, CT, 8, true>}, {&launch_k8<W8, CT, 10, false>, &launch_k8<W8, CT, 10, true>}}; };   // [NWB 8 / 10][fused]
+static const K8Row<false, 1> kK8_16_1; static const K8Row<false, 2> kK8_16_2; static const K8Row<false, 4> kK8_16_4;
+static const K8Row<true, 1> kK8_8_1; static const K8Row<true, 2> kK8_8_2; static const K8Row<true, 4> kK8_8_4;
+static k8_launch_fn k8_fn(bool w8, int ct, int nwb, bool fused) {
+    const int i = nwb == 10, f = fused;
+    if (w8) return ct == 1 ? kK8_8_1.fn[i][f] : (ct == 2 ? kK8_8_2.fn[i][f] : kK8_8_4.fn[i][f]);
+    return ct == 1 ? kK8_16_1.fn[i][f] : (ct == 2 ? kK8_16_2.fn[i][f] : kK8_16_4.fn[i][f]);
+}
 
 // The 8-phase kernels stage up to 96 KB of x in dynamic LDS: the opt-in attribute is per function AND per device, so it is set for every
 // instantiation when a context is created on a device (pgv_ctx_create), never lazily inside a launch (which may sit in a graph capture).
-template <bool W8, int CT>
+template <bool W8, int CT, int NWB, bool FUSED>
 static int configure_k8() {
-    PGV_HIP(hipFuncSetAttribute((const void*)gemv_k8_kernel<TF16, W8, CT, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
-    PGV_HIP(hipFuncSetAttribute((const void*)gemv_k8_kernel<TBF16, W8, CT, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
+    PGV_HIP(hipFuncSetAttribute((const void*)gemv_k8_kernel<TF16, W8, CT, NWB, FUSED>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
+    PGV_HIP(hipFuncSetAttribute((const void*)gemv_k8_kernel<TBF16, W8, CT, NWB, FUSED>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
+    return PGV_OK;
+}
+template <bool W8, int CT>
+static int configure_k8_row() {
+    PGV_TRY((configure_k8<W8, CT, 8, false>())); PGV_TRY((configure_k8<W8, CT, 8, true>()));
+    PGV_TRY((configure_k8<W8, CT, 10, false>())); PGV_TRY((configure_k8<W8, CT, 10, true>()));
     return PGV_OK;
 }
 int pgv_gemv_configure(pgv_ctx*) {
-    PGV_TRY((configure_k8<false, 1>())); PGV_TRY((configure_k8<false, 2>())); PGV_TRY((configure_k8<false, 4>()));
-    PGV_TRY((configure_k8<true, 1>())); PGV_TRY((configure_k8<true, 2>())); PGV_TRY((configure_k8<true, 4>()));
+    PGV_TRY((configure_k8_row<false, 1>())); PGV_TRY((configure_k8_row<false, 2>())); PGV_TRY((configure_k8_row<false, 4>()));
+    PGV_TRY((configure_k8_row<true, 1>())); PGV_TRY((configure_k8_row<true, 2>())); PGV_TRY((configure_k8_row<true, 4>()));
     return PGV_OK;
 }
 
-struct GemvChoice { int tl, ct; bool x2, k8; };
+struct GemvChoice { int tl, ct; bool x2, k8; int nwb; bool fused; };
 
 // TL = row blocks per workgroup (they share the x fragments), CT = column tiles, x2 = merged x load, k8 = the 8-phase residual producer.
 static GemvChoice choose_gemv(int mode, bool w8, int B, int grid, int K, int num_cu, bool have_k8_scratch) {
-    GemvChoice c{1, B <= 16 ? 1 : (B <= 32 ? 2 : 4), B <= 8 && lab_switch("PGV_GEMV_X2", 1) != 0, false};
-    const bool k8_ok = have_k8_scratch && lab_switch("PGV_GEMV_K8", 1) != 0 && grid % 8 == 0;
+    GemvChoice c{1, B <= 16 ? 1 : (B <= 32 ? 2 : 4), B <= 8 && lab_switch("PGV_GEMV_X2", 1) != 0, false, 8, false};
+    // row blocks (= waves) per 8-phase workgroup: 8, or 10 where that makes (row groups x 8 phases) exactly one workgroup per CU (13B: 320 row
+    // blocks -> 32 groups x 8 = 256 workgroups of 10 waves instead of 320 of 8 = 1 1/4 rounds).  The (row block, phase) partition and the phase
+    // order of the sums do not depend on it: bitwise the same result.
+    if (lab_switch("PGV_GEMV_K8_NWB10", K8_NWB10_DEFAULT) != 0 && grid % 10 == 0 && grid / 10 * 8 == num_cu) c.nwb = 10;
+    c.fused = lab_switch("PGV_GEMV_K8_FUSED", K8_FUSED_DEFAULT) != 0;
+    const bool k8_ok = have_k8_scratch && lab_switch("PGV_GEMV_K8", 1) != 0 && grid % c.nwb == 0;
     if (B > 16) {
         // Wide batches re-read 2 - 4 x the activation lines per workgroup, so the row blocks that share them matter more: qkv 3, gate/up two
         // (gate, up) pairs when the block counts divide (4 row blocks x 4 column tiles spill).
@@ -648,7 +727,7 @@ static GemvChoice choose_gemv(int mode, bool w8, int B, int grid, int K, int num
         case GV_RESIDNORM:
             // fp8 down_proj of the 13B shapes (K = 13 824, 320 row blocks): a 16-row workgroup requests as many activation lines as weight lines
             // (LAB.md "what the activation operand costs"); the 8-phase form reads 1/8 of x per workgroup and is bitwise the same result
-            c.k8 = w8 && k8_ok && K >= lab_switch("PGV_GEMV_K8_NARROW_MINK", 12288);
+            c.k8 = w8 && k8_ok && K >= lab_switch("PGV_GEMV_K8_NARROW_MINK", K8_NARROW_MINK_DEFAULT);
             break;
         default: break;
     }
@@ -678,10 +757,10 @@ int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void
     // W must be in the fragment-blocked layout with its row count padded to a multiple of 16 (zero rows)
     if (mode == GV_SWIGLU) { PGV_CHECK(N % 64 == 0, "gemv swiglu: N=%d must be a multiple of 64", N); grid = N / 32; }
     else { if (mode != GV_F32) PGV_CHECK(N % 16 == 0, "gemv: N=%d must be a multiple of 16", N); grid = (N + 15) / 16; }
-    const GemvChoice c = choose_gemv(mode, w8, B, grid, K, ctx->num_cu, norm && norm->k8_part);
+    const GemvChoice c = choose_gemv(mode, w8, B, grid, K, ctx->num_cu, norm && norm->k8_part && norm->k8_ticket);
     pgv_prof_begin(ctx, 3, s);
     if (c.k8) {
-        PGV_TRY(kK8[w8][c.ct == 1 ? 0 : (c.ct == 2 ? 1 : 2)](dtype, a, grid, norm->k8_part, s));
+        PGV_TRY(k8_fn(w8, c.ct, c.nwb, c.fused)(dtype, a, grid, norm->k8_part, norm->k8_ticket, s));
     } else {
         const GemvShape* shape = nullptr;
         for (const GemvShape& g : kGemvShapes)

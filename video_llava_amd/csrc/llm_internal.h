@@ -9,6 +9,8 @@ enum { GV_STORE16 = 0, GV_RESID = 1, GV_SWIGLU = 2, GV_F32 = 3, GV_RESIDNORM = 5
 enum { AM_INC_POS = 1, AM_RECORD = 2, AM_SAMPLE = 4 };                                  // sampling.hip bookkeeping flags
 constexpr int kDattnSplitMax = 8, kDattnPart = kHD + 2;                                 // decode_attn.hip: context splits, floats per partial state
 
+// vit_attn.hip
+int pgv_vit_attn_configure(pgv_ctx* ctx);  // per-device dynamic-LDS opt-in of the attention kernels: called once per context
 // elementwise.hip
 int pgv_launch_rmsnorm(int dtype, const float* x, const float* g, float eps, void* y, int rows, int cols, hipStream_t s);
 // llm_prefill.hip

@@ -44,8 +44,33 @@ struct AttnArgs {
 #define PGV_ATTN_ABL(p) 0          // the release library has no garbage-producing ablation switch (documented A/B switches: INTEGRATION.md)
 #endif
 
-template <typename T, int ABL>
-__global__ __launch_bounds__(256) void vit_attn_kernel(AttnArgs p) {
+// cross-half (lane l <-> l + 32) maximum with gfx950's half swap: one VALU op instead of a ds_bpermute round trip through the LDS crossbar.
+// Inline asm with two read-write operands: the builtin called with ONE value on both operands reads the second result from the wrong
+// register under hipcc 7.2 (gemv.hip rows_sum_to_row3).
+__device__ __forceinline__ float half_swap_max(float v) {
+    float a = v, b = v;
+    asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));      // lanes 0-31: (own, partner's); lanes 32-63: (partner's, own)
+    return fmaxf(a, b);
+}
+__device__ __forceinline__ float half_swap_sum(float v) {
+    float a = v, b = v;
+    asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+
+// Lazy rescale of the online softmax (round 5): the running maximum m only has to BOUND the scores loosely -- p = exp2(s - m) stays exact in
+// fp32 and representable in 16 bits as long as s - m <= LAZY_TH -- so the accumulator rescale (32 multiplies + an exp2 per chunk, and a
+// dependency between the softmax and the P.V MFMAs) runs only when some query of the wave saw a score more than LAZY_TH (log2 units) above
+// its running maximum: after the first chunk practically never.  Mathematically identical (every term carries the same factor exp2(-m), which
+// cancels against the row sum); P <= 2^LAZY_TH = 64 is far inside fp16 / bf16 range, relative rounding unchanged.
+#ifndef PGV_LAB_ATTN_LAZY_TH
+#define PGV_LAB_ATTN_LAZY_TH 6.0f      // lab: -DPGV_LAB_ATTN_LAZY_TH=-1.0f restores the rescale on every chunk
+#endif
+
+// NWAVES = waves per workgroup: 4 where two workgroups share a CU (K + V of a head <= 80 KiB: 224 px), 8 where only one fits (336 px: 152 KiB)
+// so that every SIMD still has two waves whose MFMA and softmax phases overlap.
+template <typename T, int ABL, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void vit_attn_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -119,34 +144,38 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(AttnArgs p) {
 
     // S^T of one chunk: key blocks past the end re-read the last one (valid LDS, masked in the softmax) so there are no branches, the 12
     // fragment reads are issued together and the MFMAs of the three independent accumulators interleave.
-    auto scores = [&](int kb0, const typename T::v8 (&qf)[4], f32x16_t (&s)[CB]) __attribute__((always_inline)) {
-        typename T::v8 kf[CB][4];
+    // NB (compile time) = key blocks of this chunk: CB for every full chunk; the LAST chunk runs with exactly the blocks that exist (1..CB), so
+    // N = 577 (19 blocks = 6 chunks + 1 block) no longer pays for two dummy blocks of MFMAs and exponentials per query block.
+    auto scores = [&](int kb0, const typename T::v8 (&qf)[4], f32x16_t (&s)[CB], auto nb_tag) __attribute__((always_inline)) {
+        constexpr int NB = decltype(nb_tag)::value;
+        typename T::v8 kf[NB][4];
 #pragma unroll
-        for (int c = 0; c < CB; ++c) {
-            const char* kr = Ks + (size_t)(min(kb0 + c, p.nkb - 1) * 32 + l31) * 128;
+        for (int c = 0; c < NB; ++c) {
+            const char* kr = Ks + (size_t)((kb0 + c) * 32 + l31) * 128;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) kf[c][kk] = *(const typename T::v8*)(kr + koffs[kk]);
         }
 #pragma unroll
-        for (int c = 0; c < CB; ++c)
+        for (int c = 0; c < NB; ++c)
 #pragma unroll
             for (int e = 0; e < 16; ++e) s[c][e] = 0.f;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-            for (int c = 0; c < CB; ++c) {
+            for (int c = 0; c < NB; ++c) {
                 if constexpr ((ABL & 32) != 0) { s[c][kk] += (float)kf[c][kk][0] * (float)qf[kk][0]; continue; }
                 s[c] = T::mfma32(kf[c][kk], qf[kk], s[c]);
             }
     };
     // Online-softmax update with one chunk of scores and O^T += V^T . P^T.  MASK: the chunk may hold keys >= N.
-    auto absorb = [&](int kb0, f32x16_t (&s)[CB], f32x16_t (&o)[2], float& mrun, float& lrun, auto mask_tag) __attribute__((always_inline)) {
+    auto absorb = [&](int kb0, f32x16_t (&s)[CB], f32x16_t (&o)[2], float& mrun, float& lrun, auto mask_tag, auto nb_tag) __attribute__((always_inline)) {
         constexpr bool MASK = decltype(mask_tag)::value;
+        constexpr int NB = decltype(nb_tag)::value;
         // V^T fragments of the chunk: issued first, their LDS latency hides under the softmax arithmetic
-        typename T::v8 vf[CB][2][2];
+        typename T::v8 vf[NB][2][2];
 #pragma unroll
-        for (int c = 0; c < CB; ++c) {
-            const char* vb = Vs + (size_t)min(kb0 + c, p.nkb - 1) * 4096;
+        for (int c = 0; c < NB; ++c) {
+            const char* vb = Vs + (size_t)(kb0 + c) * 4096;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -158,15 +187,13 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(AttnArgs p) {
                 }
         }
         if constexpr (MASK) {
+            constexpr int c = NB - 1;                            // only the last existing block can hold keys >= N
+            if ((kb0 + c + 1) * 32 > N) {                        // wave-uniform
+                const int kbase_idx = (kb0 + c) * 32 + 4 * hi;
 #pragma unroll
-            for (int c = 0; c < CB; ++c) {
-                if ((kb0 + c + 1) * 32 > N) {                    // wave-uniform: only blocks that hold padding pay for the compares
-                    const int kbase_idx = (kb0 + c) * 32 + 4 * hi;
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int key = kbase_idx + (e & 3) + 8 * (e >> 2);
-                        s[c][e] = (key < N) ? s[c][e] : NEG;     // also covers kb0+c >= nkb (key >= npad >= N)
-                    }
+                for (int e = 0; e < 16; ++e) {
+                    const int key = kbase_idx + (e & 3) + 8 * (e >> 2);
+                    s[c][e] = (key < N) ? s[c][e] : NEG;
                 }
             }
         }
@@ -174,19 +201,27 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(AttnArgs p) {
         if constexpr ((ABL & 64) != 0) cmax = s[0][0];
         else {
 #pragma unroll
-            for (int c = 0; c < CB; ++c)
+            for (int c = 0; c < NB; ++c)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) cmax = fmaxf(cmax, s[c][e]);
-            cmax = fmaxf(cmax, __shfl_xor(cmax, 32, 64));
+            cmax = half_swap_max(cmax);
         }
-        const float mnew = fmaxf(mrun, cmax * p.scale_log2e);
-        const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
-        mrun = mnew;
+        const float cm = cmax * p.scale_log2e;
+        if (__builtin_amdgcn_ballot_w64(cm > mrun + PGV_LAB_ATTN_LAZY_TH) != 0ull) {      // wave-uniform; always taken on a block's first chunk (mrun = NEG)
+            const float mnew = fmaxf(mrun, cm);
+            const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+            mrun = mnew;
+            lrun *= alpha;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[j][e] *= alpha;
+        }
         // p = exp2(s * scale - m): one packed FMA per two scores, packed partial sums
-        const f32x2_t sc2 = {p.scale_log2e, p.scale_log2e}, nm2 = {-mnew, -mnew};
+        const f32x2_t sc2 = {p.scale_log2e, p.scale_log2e}, nm2 = {-mrun, -mrun};
         f32x2_t psum2 = {0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < CB; ++c)
+        for (int c = 0; c < NB; ++c)
 #pragma unroll
             for (int e = 0; e < 16; e += 2) {
                 const f32x2_t x = f32x2_t{s[c][e], s[c][e + 1]} * sc2 + nm2;
@@ -194,13 +229,9 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(AttnArgs p) {
                 s[c][e] = pv[0]; s[c][e + 1] = pv[1];
                 psum2 += pv;
             }
-        lrun = lrun * alpha + (psum2[0] + psum2[1]);
+        lrun += psum2[0] + psum2[1];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) o[j][e] *= alpha;
-#pragma unroll
-        for (int c = 0; c < CB; ++c)
+        for (int c = 0; c < NB; ++c)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 typename T::v8 pa;
@@ -233,14 +264,17 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(AttnArgs p) {
         f32x16_t s[CB];
         int kb0 = 0;
         for (; kb0 + CB < p.nkb; kb0 += CB) {
-            scores(kb0, qf, s);
-            absorb(kb0, s, o, mrun, lrun, std::false_type{});
+            scores(kb0, qf, s, std::integral_constant<int, CB>{});
+            absorb(kb0, s, o, mrun, lrun, std::false_type{}, std::integral_constant<int, CB>{});
         }
-        scores(kb0, qf, s);
-        absorb(kb0, s, o, mrun, lrun, std::true_type{});     // only the last chunk can hold keys >= N
+        // the last chunk holds 1..CB blocks (wave-uniform) and is the only one that can hold keys >= N
+        const int rem = p.nkb - kb0;
+        if (rem == 1) { scores(kb0, qf, s, std::integral_constant<int, 1>{}); absorb(kb0, s, o, mrun, lrun, std::true_type{}, std::integral_constant<int, 1>{}); }
+        else if (rem == 2) { scores(kb0, qf, s, std::integral_constant<int, 2>{}); absorb(kb0, s, o, mrun, lrun, std::true_type{}, std::integral_constant<int, 2>{}); }
+        else { scores(kb0, qf, s, std::integral_constant<int, CB>{}); absorb(kb0, s, o, mrun, lrun, std::true_type{}, std::integral_constant<int, CB>{}); }
 
         __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the next block's Q (requested a whole block ago); see load_q
-        const float ltot = lrun + __shfl_xor(lrun, 32, 64);
+        const float ltot = half_swap_sum(lrun);
         const float inv = 1.0f / ltot;
         const int q = qb * 32 + l31;
         // Output row q lives in the lane pair (q, q + 32): 4 consecutive d per accumulator group, alternating between the two lanes.  Two
@@ -281,12 +315,15 @@ int pgv_launch_vit_attn(pgv_ctx* ctx, int dtype, const void* qkv, int ld, void* 
 #endif
     const size_t lds = (size_t)npad * 256 + 16;    // K + V images + the query-block counter
     PGV_CHECK(lds <= 160 * 1024, "vit_attn: %d tokens per frame need %zu B of LDS (> 160 KiB)", N, lds);
-    const int nw = 4;
+    static_assert(CB == 3, "the last-chunk dispatch above enumerates 1..3 blocks");
+    bool one_wg_per_cu = lds > 80 * 1024;            // 336 px: K + V of a head fill the CU's LDS -> 8 waves so that every SIMD still holds two
+#ifdef PGV_LAB
+    { static int f = -1; if (f < 0) { const char* e = getenv("PGV_ATTN_NW4"); f = e ? atoi(e) : 0; } if (f) one_wg_per_cu = false; }     // lab A/B: 4 waves everywhere
+#endif
     pgv_prof_begin(ctx, 1, s);
 #define PGV_ATTN_LAUNCH(T_, ABL_) do { \
-        static bool cfg = false; \
-        if (!cfg) { PGV_HIP(hipFuncSetAttribute((const void*)vit_attn_kernel<T_, ABL_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); cfg = true; } \
-        hipLaunchKernelGGL((vit_attn_kernel<T_, ABL_>), dim3(T * heads), dim3(nw * 64), lds, s, a); } while (0)
+        if (one_wg_per_cu) hipLaunchKernelGGL((vit_attn_kernel<T_, ABL_, 8>), dim3(T * heads), dim3(512), lds, s, a); \
+        else hipLaunchKernelGGL((vit_attn_kernel<T_, ABL_, 4>), dim3(T * heads), dim3(256), lds, s, a); } while (0)
     if (dtype == PGV_F16) {
         PGV_ATTN_LAUNCH(TF16, 0);
     } else if (dtype == PGV_BF16) {
@@ -312,6 +349,31 @@ int pgv_launch_vit_attn(pgv_ctx* ctx, int dtype, const void* qkv, int ld, void* 
 #undef PGV_ATTN_LAUNCH
     PGV_HIP(hipGetLastError());
     pgv_prof_end(ctx, 1, s, 4.0 * (double)T * heads * (double)N * N * HD, 2.0 * 4.0 * (double)T * N * C);
+    return PGV_OK;
+}
+
+// Dynamic-LDS opt-in of every instantiation, per device, at context creation (not lazily under a process-wide flag: ADVICE r4 on gemv.hip).
+int pgv_vit_attn_configure(pgv_ctx*) {
+    PGV_HIP(hipFuncSetAttribute((const void*)vit_attn_kernel<TF16, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PGV_HIP(hipFuncSetAttribute((const void*)vit_attn_kernel<TF16, 0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PGV_HIP(hipFuncSetAttribute((const void*)vit_attn_kernel<TBF16, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PGV_HIP(hipFuncSetAttribute((const void*)vit_attn_kernel<TBF16, 0, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#ifdef PGV_LAB
+    PGV_HIP(hipFuncSetAttribute((const void*)vit_attn_kernel<TBF16, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PGV_HIP(hipFuncSetAttribute((const void*)vit_attn_kernel<TBF16, 16, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PGV_HIP(hipFuncSetAttribute((const void*)vit_attn_kernel<TBF16, 32, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PGV_HIP(hipFuncSetAttribute((const void*)vit_attn_kernel<TBF16, 64, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PGV_HIP(hipFuncSetAttribute((const void*)vit_attn_kernel<TBF16, 48, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PGV_HIP(hipFuncSetAttribute((const void*)vit_attn_kernel<TBF16, 72, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PGV_HIP(hipFuncSetAttribute((const void*)vit_attn_kernel<TBF16, 120, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PGV_HIP(hipFuncSetAttribute((const void*)vit_attn_kernel<TBF16, 8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PGV_HIP(hipFuncSetAttribute((const void*)vit_attn_kernel<TBF16, 16, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PGV_HIP(hipFuncSetAttribute((const void*)vit_attn_kernel<TBF16, 32, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PGV_HIP(hipFuncSetAttribute((const void*)vit_attn_kernel<TBF16, 64, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PGV_HIP(hipFuncSetAttribute((const void*)vit_attn_kernel<TBF16, 48, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PGV_HIP(hipFuncSetAttribute((const void*)vit_attn_kernel<TBF16, 72, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PGV_HIP(hipFuncSetAttribute((const void*)vit_attn_kernel<TBF16, 120, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#endif
     return PGV_OK;
 }
 
