@@ -21,7 +21,8 @@ video_chatgpt/model/video_chatgpt.py:193-251 driven over 32 / 40 layers by the g
     -> 256 FREE-RUNNING greedy tokens (the bench's horizon: prompt + 256), with the fp32 oracle chain (ovis.clip_select_features on all 100
     frames -> pool -> ollm.LlamaOracle) evaluated at EVERY visited position in one causal pass over prompt + the HIP path's own tokens.
     By induction, as long as the HIP token is the oracle's argmax the oracle's own free run is the same sequence; `exact prefix` is that
-    length (asserted >= 64 in fp16: the clip / prompt pair was picked on the GPU so that no 16-bit near-tie flips before).  Beyond the
+    length (asserted >= 128 in fp16; measured 243 of 256 tokens at 7B and all 256 at 13B fp8, with 255 / 256 resp. 256 / 256 tokens equal to
+    the oracle's argmax given the same prefix; in bf16, the benched dtype, 236 / 256 and 239 / 256).  Beyond the
     first near-tie flip the comparison stays meaningful because the oracle is evaluated on the HIP path's prefix: at every position whose
     oracle margin exceeds 6 sigma of the measured per-logit noise the token must be the oracle's argmax, everywhere the chosen token's
     oracle logit must be within that bound of the best, and the logits error is bounded at all 256 positions (every KV position bench.py
@@ -61,12 +62,14 @@ YARD_FACTOR = 1.25
 TOL_7B_FP16 = 8.1e-3        # regression pin: 1.2 x 6.72e-3 (2 layers: 1.84e-3; x sqrt(16): independent 16-bit roundings per layer, fp32 residual)
 TOL_13B_FP8_FP16 = 1.33e-2  # regression pin: 1.2 x the worst decode step measured (1.105e-2; prefill 6.98e-3)
 # end-to-end cases: worst logits error over the 256 free-running positions (1.2 x measured on MI355X) and the exact prefix of the fp16 runs
-E2E_PIN_7B_FP16 = float(os.environ.get("PGV_E2E_PIN", 1.5e-2))
-E2E_PIN_7B_BF16 = float(os.environ.get("PGV_E2E_PIN", 1.2e-1))
-E2E_PIN_13B_FP16 = float(os.environ.get("PGV_E2E_PIN", 2.2e-2))
-E2E_PIN_13B_BF16 = float(os.environ.get("PGV_E2E_PIN", 1.6e-1))
-E2E_PREFIX_7B_FP16 = int(os.environ.get("PGV_E2E_PREFIX", 64))
-E2E_PREFIX_13B_FP16 = int(os.environ.get("PGV_E2E_PREFIX", 64))
+# (measured, gpurun_out/r5a: 7B fp16 worst 2.75e-3, exact prefix 243 of 256 tokens, 255 / 256 == the oracle's argmax; 7B bf16 worst 2.86e-2, 236 / 256;
+#  13B fp8 fp16 worst 4.85e-3, exact prefix 256 = the whole run; 13B fp8 bf16 worst 4.97e-2, 239 / 256)
+E2E_PIN_7B_FP16 = float(os.environ.get("PGV_E2E_PIN", 3.3e-3))
+E2E_PIN_7B_BF16 = float(os.environ.get("PGV_E2E_PIN", 3.5e-2))
+E2E_PIN_13B_FP16 = float(os.environ.get("PGV_E2E_PIN", 5.9e-3))
+E2E_PIN_13B_BF16 = float(os.environ.get("PGV_E2E_PIN", 6.0e-2))
+E2E_PREFIX_7B_FP16 = int(os.environ.get("PGV_E2E_PREFIX", 128))     # >= 64 is the bar; 243 measured: the first 16-bit near-tie flip of this clip / prompt pair
+E2E_PREFIX_13B_FP16 = int(os.environ.get("PGV_E2E_PREFIX", 128))    # 256 measured
 
 
 def _yard(golden_dir, case, truth_logits):
@@ -297,8 +300,8 @@ def test_7b_full_depth_fp16_token_exact(ctx, golden_dir):
 def test_7b_config3_end_to_end_fp16_256_free_running_tokens(ctx):
     """BASELINE config 3 as video_chatgpt/inference.py:47-124 runs it, in the reference's dtype: 100 uint8 frames -> ... -> 256 free-running greedy
     tokens; see the module docstring for the criterion."""
-    _e2e("7b fp16 e2e", "7b", torch.float16, False, min_decisive=int(0.6 * N_FREE), min_exact_prefix=E2E_PREFIX_7B_FP16, pin_worst=E2E_PIN_7B_FP16,
-         sigma_cap=0.05)
+    st = _e2e("7b fp16 e2e", "7b", torch.float16, False, min_decisive=200, min_exact_prefix=E2E_PREFIX_7B_FP16, pin_worst=E2E_PIN_7B_FP16, sigma_cap=0.02)
+    assert st["agree"] >= 250        # 255 measured
 
 
 def _bench_call_check(tag, name, dtype, fp8):
@@ -391,7 +394,8 @@ def test_7b_full_depth_bf16_teacher_forced(ctx, golden_dir):
 
 def test_7b_config3_end_to_end_bf16_256_free_running_tokens(ctx):
     """Config 3 end to end in the BENCHED dtype: bf16 noise is 8x fp16's, so fewer positions are decisive; same criterion."""
-    _e2e("7b bf16 e2e", "7b", torch.bfloat16, False, min_decisive=24, min_exact_prefix=0, pin_worst=E2E_PIN_7B_BF16)
+    st = _e2e("7b bf16 e2e", "7b", torch.bfloat16, False, min_decisive=100, min_exact_prefix=0, pin_worst=E2E_PIN_7B_BF16, sigma_cap=0.15)
+    assert st["agree"] >= 220        # 236 measured (the reference's own bf16 run agrees at 80 / 97 = 82 % of teacher-forced positions; this is 92 %)
 
 
 def test_7b_bench_call_bf16_equals_single_clip_runs(ctx):
@@ -432,8 +436,8 @@ def test_13b_full_depth_fp8_weights_fp16_token_exact(ctx, golden_dir):
 def test_13b_config5_end_to_end_fp8_fp16_256_free_running_tokens(ctx):
     """Config 5 end to end (13B, 40 layers, e4m3 weights, fp16 activations): 100 frames -> 256 free-running tokens vs the fp32 oracle chain on the
     dequantised weights."""
-    _e2e("13b fp8 fp16 e2e", "13b", torch.float16, True, min_decisive=int(0.5 * N_FREE), min_exact_prefix=E2E_PREFIX_13B_FP16, pin_worst=E2E_PIN_13B_FP16,
-         sigma_cap=0.08)
+    st = _e2e("13b fp8 fp16 e2e", "13b", torch.float16, True, min_decisive=190, min_exact_prefix=E2E_PREFIX_13B_FP16, pin_worst=E2E_PIN_13B_FP16, sigma_cap=0.035)
+    assert st["agree"] >= 250        # 256 measured
 
 
 def test_13b_full_depth_fp8_weights_bf16_teacher_forced(ctx, golden_dir):
@@ -448,7 +452,8 @@ def test_13b_full_depth_fp8_weights_bf16_teacher_forced(ctx, golden_dir):
 
 def test_13b_config5_end_to_end_fp8_bf16_256_free_running_tokens(ctx):
     """Config 5 end to end as bench.py's side line runs it (bf16 activations)."""
-    _e2e("13b fp8 bf16 e2e", "13b", torch.bfloat16, True, min_decisive=16, min_exact_prefix=0, pin_worst=E2E_PIN_13B_BF16)
+    st = _e2e("13b fp8 bf16 e2e", "13b", torch.bfloat16, True, min_decisive=60, min_exact_prefix=0, pin_worst=E2E_PIN_13B_BF16, sigma_cap=0.3)
+    assert st["agree"] >= 220        # 239 measured (the reference's own bf16 run on these weights: 107 / 161 = 66 %; this is 93 %)
 
 
 def test_13b_bench_call_fp8_bf16_equals_single_clip_runs(ctx):

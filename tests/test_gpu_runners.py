@@ -324,15 +324,14 @@ def test_generate_stop_string_ahead_of_eos_in_the_same_chunk(ctx):
     that appears BEFORE that EOS in the same chunk (the per-token loop of the reference, model/utils.py:6-26, stops at the string first)."""
     from video_llava_amd.inference import build_prompt
     ccfg, lcfg, cw, lw, tower, model, ip, V = _tiny_components()
-    frames = synth.make_frames(6, ccfg.image, seed=77)
+    frames = synth.make_frames(5, ccfg.image, seed=60)
     pooled = ovis.spatio_temporal_pool_torch(ovis.clip_select_features(ovis.clip_preprocess(frames), cw, ccfg)).half().to(DEV)[None]
-    prompt, _ = build_prompt("what happens?", "default", V, True)
+    prompt, _ = build_prompt("what happens 0?", "default", V, True)
     ids = _Tok(lcfg.vocab)([prompt]).input_ids[0]
     free = model.generate([ids], video_spatio_temporal_features=pooled, do_sample=False, max_new_tokens=40)[0, len(ids):].tolist()
-    def fresh(upto):
-        return next(i for i in range(upto, 0, -1) if free[i] not in free[:i])
-    i_stop = fresh(6)
-    i_eos = next(i for i in range(i_stop + 1, 30) if free[i] not in free[:i])              # a later fresh token plays EOS: both inside the first chunk of 32
+    first = [i for i in range(1, 30) if free[i] not in free[:i]]                           # positions >= 1 where a token occurs for the first time
+    assert len(first) >= 2, (free, "the free run has fewer than three distinct tokens in its first chunk: pick another clip / question")
+    i_stop, i_eos = first[0], first[1]                                                     # stop string first, a later fresh token plays EOS: both inside the first chunk of 32
     tok = _StopTok(lcfg.vocab, {free[i_stop]})
     out = model.generate([ids], video_spatio_temporal_features=pooled, do_sample=False, max_new_tokens=40, eos_token_id=free[i_eos],
                          stop_strings=["###"], tokenizer=tok, chunk=32)
@@ -418,7 +417,7 @@ torch.distributed.destroy_process_group()
     env.pop("PGV_DIST_BACKEND", None)
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and "ANSWERS" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
-    line = r.stdout.split("ANSWERS", 1)[1].strip()
+    line = r.stdout.split("ANSWERS", 1)[1].strip().splitlines()[0]                         # (RCCL prints its version banner to stdout at teardown)
     ans = json.loads(line[:line.rindex("]") + 1])
     assert ans == [[100 * i + t for t in range(6 - (i % 3))] for i in range(5)]
     assert line.endswith("4.0")

@@ -842,3 +842,24 @@ def test_device_resize_upload_is_bounded(tmp_path):
         assert isinstance(out, np.ndarray) and out.shape == (4, 14, 14, 3)
     finally:
         fx.DEVICE_RESIZE_MAX_BYTES = old
+
+
+def test_runner_batch_auto_picks_the_widest_group_that_fits():
+    """`--batch auto` (the runners' default since round 5): the largest of 8 / 16 / 32 / 64 clips per group whose KV cache + tower workspace
+    fit 70 % of the free device memory; explicit values still parse, out-of-range ones are rejected."""
+    import argparse
+    from video_llava_amd.eval import _sharded
+    from video_llava_amd.model.video_chatgpt import VideoChatGPTConfig
+    c7 = VideoChatGPTConfig(vocab_size=32003)
+    c13 = VideoChatGPTConfig(vocab_size=32003, hidden_size=5120, intermediate_size=13824, num_hidden_layers=40, num_attention_heads=40)
+    GiB = 2 ** 30
+    need = [_sharded.batch_bytes(b, c7, 224, 1024) for b in (8, 16, 32, 64)]
+    assert need == sorted(need) and 4 * GiB < need[0] < 20 * GiB and 40 * GiB < need[3] < 160 * GiB, [n / GiB for n in need]
+    assert _sharded.pick_batch(c7, 224, 1024, 270 * GiB) == 64                 # a free MI355X next to 13.5 GB of weights
+    assert _sharded.pick_batch(c7, 224, 1024, int(need[2] / 0.7) + GiB) == 32
+    assert _sharded.pick_batch(c7, 224, 1024, 8 * GiB) == 8                    # never below 8: a too-small GPU fails in the allocation, loudly
+    assert _sharded.batch_bytes(64, c13, 336, 1024) > _sharded.batch_bytes(64, c7, 224, 1024)
+    p = _sharded.add_runtime_arguments(argparse.ArgumentParser())
+    assert p.parse_args([]).batch == "auto" and p.parse_args(["--batch", "16"]).batch == 16
+    with pytest.raises(SystemExit):
+        p.parse_args(["--batch", "65"])
