@@ -183,8 +183,11 @@ def runner_measurement(args, model, tower, video_rows, S, rank, world):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-PMC_PREFIX = {"gemm": "gemm_w4", "vit_attn": "vit_attn_kernel", "llm_prefill_attn": "prefill_attn_kernel",
-              "decode_gemv": "gemv_mfma_kernel", "decode_attn": "decode_attn_kernel"}
+# kernel-name prefixes of a family in the rocprofv3 tables; a name in PMC_SECONDARY belongs to a launch of the family that a primary kernel already
+# counts (the finish launch of the 8-phase residual producers): its bytes are added, its calls are not
+PMC_PREFIX = {"gemm": ("gemm_w4",), "vit_attn": ("vit_attn_kernel",), "llm_prefill_attn": ("prefill_attn_kernel",),
+              "decode_gemv": ("gemv_mfma_kernel", "gemv_k8_kernel", "gemv_k8_finish_kernel"), "decode_attn": ("decode_attn_kernel", "decode_attn_split_kernel")}
+PMC_SECONDARY = ("gemv_k8_finish_kernel",)
 
 
 def pmc_traffic(family, tag="traffic"):
@@ -202,7 +205,8 @@ def pmc_traffic(family, tag="traffic"):
     calls = tot = 0.0
     for name, r in d.items():
         if name.startswith(PMC_PREFIX[family]) and r.get("fetch_bytes_corrected_x2") is not None:
-            calls += r["calls"]
+            if not name.startswith(PMC_SECONDARY):
+                calls += r["calls"]
             tot += r["calls"] * (r["fetch_bytes_corrected_x2"] + (r.get("write_bytes_raw") or 0.0))
     if calls == 0:
         return {"traffic": None}

@@ -342,6 +342,34 @@ def test_vit_336_even_row_count(ctx, dtype, tol):
     assert rel(full[:3, 1:], ref) < tol
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 1e-3), (torch.bfloat16, 8e-3)])
+def test_vit_336_100_frames_production_shape(ctx, dtype, tol):
+    """The PRODUCTION tower of the released PG-Video-LLaVA weights at the size a clip has: ViT-L/14-336, 100 frames x 577
+    tokens in one call (two lanes of 50 frames; the attention kernel runs its 8-wave form: K + V of a head fill a CU's LDS).  The pass must equal
+    the reference's infer_batch = 32 loop (scripts/save_spatio_temporal_clip_features.py:108-121) bit for bit, a frame permutation must
+    permute the output, the first 3 frames are held to the fp32 oracle, and the pooled [100 + 576, 1024] video tokens to the oracle's pooling
+    of the same features."""
+    cfg = synth.CLIP_L14_336
+    w = synth.make_clip_weights(cfg, seed=3)
+    tower = _tower(cfg, w, dtype)
+    frames = np.concatenate([synth.make_frames(3, 336, seed=4), synth.make_frames(97, 336, seed=6)])
+    px = ctx.preprocess_u8(torch.from_numpy(frames).to(DEV), dtype)
+    full = tower(px).hidden_states[-2]
+    assert full.shape == (100, 577, 1024) and torch.isfinite(full).all()
+    parts = torch.cat([tower(px[i:i + 32]).hidden_states[-2] for i in range(0, 100, 32)])
+    assert torch.equal(full, parts)
+    perm = torch.randperm(100, generator=torch.Generator().manual_seed(1)).to(DEV)
+    assert torch.equal(tower(px[perm]).hidden_states[-2], full[perm])
+    ref = ovis.clip_select_features(ovis.clip_preprocess(frames[:3]), w, cfg)
+    e = rel(full[:3, 1:], ref)
+    print(f"336 px, 100 frames {dtype}: first 3 frames vs fp32 oracle {e:.3e}")
+    assert e < tol
+    pooled = ctx.st_pool(full[:, 1:])
+    assert tuple(pooled.shape) == (676, 1024)
+    assert rel(pooled[100:], full[:, 1:].float().mean(0)) < 2e-3          # spatial tokens = mean over the 100 frames (fp16 output rounding)
+    assert rel(pooled[:3], ref.mean(1)) < tol                             # temporal tokens of the oracle-checked frames
+
+
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("M,N", [(102800, 3072), (102800, 4096), (4096, 3072), (4096, 4096), (205600, 3072)])
 def test_gemm_w_resident_tile_order(ctx, dtype, M, N):

@@ -356,27 +356,16 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
 // NWB row blocks (= waves) per workgroup: 8.
 // ---------------------------------------------------------------------------------------------
 // Sum of the eight phase tiles of row block rb in phase order + the epilogue of gemv_mfma_kernel<GV_RESIDNORM>, statement for statement (one wave).
-// MEMSIDE: the tiles were written by OTHER workgroups of the same launch (fused form below): read them with agent-scope relaxed atomic loads
-// (sc1: from the memory side, coherent across the XCDs) instead of plain loads.
-template <typename T, bool W8, int CT, bool MEMSIDE>
+template <typename T, bool W8, int CT>
 __device__ __forceinline__ void k8_finish_row_block(const GemvArgs& p, const f32x4_t* __restrict__ part, int rb, int lane, const f32x4_t (&r_old)[CT], f32x4_t g_nx) {
     const int l15 = lane & 15, kg = lane >> 4;
     const int n0 = rb * 16 + kg * 4;
     const f32x4_t* src = part + ((size_t)rb * 8 * CT) * 64 + lane;
-    auto ld = [&](const f32x4_t* q) -> f32x4_t {
-        if constexpr (MEMSIDE) {
-            const float* f = (const float*)q;
-            f32x4_t v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = __hip_atomic_load(f + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return v;
-        } else return *q;
-    };
     f32x4_t tile[CT][8];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-        for (int ww = 0; ww < 8; ++ww) tile[ct][ww] = ld(src + (ww * CT + ct) * 64);      // all loads in flight before the first add
+        for (int ww = 0; ww < 8; ++ww) tile[ct][ww] = src[(ww * CT + ct) * 64];      // all loads in flight before the first add
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
         f32x4_t tot = tile[ct][0];
@@ -398,15 +387,12 @@ __device__ __forceinline__ void k8_finish_row_block(const GemvArgs& p, const f32
     }
 }
 
-// FUSED (round 5): no finish launch.  Every workgroup publishes its phase tiles with agent-scope relaxed atomic stores (sc1: written through to
-// the memory side), waits for their acknowledgement, and takes a ticket of its row group; the EIGHTH arriver -- whichever phase it is -- runs the
-// finish for the row group's NWB row blocks (one per wave) reading all eight phase tiles back with sc1 loads and adding them in PHASE order:
-// the result is bitwise the finish kernel's, independent of the arrival order.  Same fence-free scheme as decode_attn_split_kernel
-// (decode_attn.hip; lowering checked at build time by build.check_isa).  The ticket is re-armed by the last arriver.
-template <typename T, bool W8, int CT, int NWB, bool FUSED>
-__global__ __launch_bounds__(NWB * 64) void gemv_k8_kernel(GemvArgs p, f32x4_t* __restrict__ part, unsigned* __restrict__ ticket) {
+// (Round 5 also built a FUSED form -- no finish launch: phase tiles published with agent-scope relaxed atomic stores, a ticket per row group,
+// the eighth arriver runs the finish -- bitwise equal, but the hand-off through the memory side costs more than the 4.8 us finish launch:
+// 13B fp8 6.53 -> 6.14 videos/s, 7B at 32 / 64 clips 16.5 -> 15.9 / 19.3 -> 17.7.  Removed; numbers in LAB.md.)
+template <typename T, bool W8, int CT, int NWB>
+__global__ __launch_bounds__(NWB * 64) void gemv_k8_kernel(GemvArgs p, f32x4_t* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) char xs[];    // [groups of this pass][B rows][128 B], 16-B chunks XORed with (row & 7)
-    __shared__ unsigned s_ticket;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kg = lane >> 4;
@@ -491,32 +477,11 @@ __global__ __launch_bounds__(NWB * 64) void gemv_k8_kernel(GemvArgs p, f32x4_t* 
         }
     }
     f32x4_t* dst = part + (((size_t)rb * 8 + j) * CT) * 64 + lane;
-    if constexpr (!FUSED) {
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) dst[ct * 64] = acc[ct];
-    } else {
-        // the finish's own operands (old residual, gamma: L2 hits) are requested by every workgroup before the hand-off, so the last arriver
-        // does not start a fresh round trip for them after the ticket
-        const int n0 = rb * 16 + kg * 4;
-        f32x4_t r_old[CT];
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) r_old[ct] = *(const f32x4_t*)(p.out + ((size_t)min(ct * 16 + l15, p.B - 1) * p.ldo + n0) * 4);
-        const f32x4_t g_nx = *(const f32x4_t*)(p.gamma + n0);
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) __hip_atomic_store((float*)(dst + ct * 64) + e, acc[ct][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this thread's write-through stores have been acknowledged ...
-        __syncthreads();                                         // ... and so have everyone's in this workgroup
-        if (tid == 0) s_ticket = __hip_atomic_fetch_add(ticket + rg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        if (s_ticket != 7u) return;                              // not the eighth arriver
-        if (tid == 0) __hip_atomic_store(ticket + rg, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // re-arm (the next launch is ordered by the kernel boundary)
-        k8_finish_row_block<T, W8, CT, true>(p, part, rb, lane, r_old, g_nx);
-    }
+    for (int ct = 0; ct < CT; ++ct) dst[ct * 64] = acc[ct];
 }
 
-// unfused form: one wave per row block (a second launch)
+// the finish launch: one wave per row block
 template <typename T, bool W8, int CT>
 __global__ __launch_bounds__(64) void gemv_k8_finish_kernel(GemvArgs p, const f32x4_t* __restrict__ part) {
     const int lane = threadIdx.x, l15 = lane & 15, kg = lane >> 4;
@@ -526,7 +491,7 @@ __global__ __launch_bounds__(64) void gemv_k8_finish_kernel(GemvArgs p, const f3
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) r_old[ct] = *(const f32x4_t*)(p.out + ((size_t)min(ct * 16 + l15, p.B - 1) * p.ldo + n0) * 4);
     const f32x4_t g_nx = *(const f32x4_t*)(p.gamma + n0);
-    k8_finish_row_block<T, W8, CT, false>(p, part, rb, lane, r_old, g_nx);
+    k8_finish_row_block<T, W8, CT>(p, part, rb, lane, r_old, g_nx);
 }
 
 // decode: resid[b] = embed[tok[b]] plus the producer side of the folded RMSNorm (see GemvArgs): xg = round16(resid * gamma of layer 0's
@@ -598,8 +563,6 @@ int pgv_launch_embed_tok_norm(int dtype, const int* tok, const void* embed, floa
 // ---------------------------------------------------------------------------------------------
 // Launch-shape A/B switches exist in the lab library only (-DPGV_LAB, never loaded by the product): PGV_GEMV_TL3, PGV_GEMV_X2, PGV_GEMV_K8,
 // PGV_GEMV_K8_NARROW_MINK.  The release library uses the defaults.
-constexpr int K8_NWB10_DEFAULT = 0, K8_FUSED_DEFAULT = 0, K8_NARROW_MINK_DEFAULT = 12288;      // round-5 experiments: defaults flip once measured
-
 static int lab_switch(const char* name, int dflt) {
 #ifdef PGV_LAB
     const char* e = getenv(name);
@@ -650,61 +613,50 @@ static const GemvShape kGemvShapes[] = {
 };
 
 // The 8-phase form of a residual producer with CT column tiles and NWB row blocks (= waves) per workgroup; `a` is complete except lds_bytes.
-// nrb = row blocks of the matrix (N / 16, a multiple of NWB): (nrb / NWB) row groups x 8 phases workgroups.
-template <bool W8, int CT, int NWB, bool FUSED>
-static int launch_k8(int dtype, GemvArgs a, int nrb, void* k8_part, unsigned* k8_ticket, hipStream_t s) {
+// nrb = row blocks of the matrix (N / 16, a multiple of NWB): (nrb / NWB) row groups x 8 phases workgroups, then the finish launch.
+template <bool W8, int CT, int NWB>
+static int launch_k8(int dtype, GemvArgs a, int nrb, void* k8_part, hipStream_t s) {
     const int gpw_max = ((a.K / 32 + 1) / 2 + 7) / 8;
     const unsigned budget = 96u * 1024u, per_group = (unsigned)CT * 16u * 128u;
     unsigned lds = (unsigned)gpw_max * per_group;
     if (lds > budget) lds = budget / per_group * per_group;
     a.lds_bytes = lds;
     f32x4_t* part = (f32x4_t*)k8_part;
-    const int grid = nrb / NWB * 8;
-    PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gemv_k8_kernel<T, W8, CT, NWB, FUSED>), dim3(grid), dim3(NWB * 64), lds, s, a, part, k8_ticket));
-    if constexpr (!FUSED) PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gemv_k8_finish_kernel<T, W8, CT>), dim3(nrb), dim3(64), 0, s, a, (const f32x4_t*)part));
+    PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gemv_k8_kernel<T, W8, CT, NWB>), dim3(nrb / NWB * 8), dim3(NWB * 64), lds, s, a, part));
+    PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gemv_k8_finish_kernel<T, W8, CT>), dim3(nrb), dim3(64), 0, s, a, (const f32x4_t*)part));
     return PGV_OK;
 }
-using k8_launch_fn = int (*)(int dtype, GemvArgs a, int nrb, void* k8_part, unsigned* k8_ticket, hipStream_t s);
-template <bool W8, int CT>
-struct K8Row { k8_launch_fn fn[2][2] = {{&launch_k8<W8, CT, 8, false>, &launch_k8<W8, CT, 8, true>}, {&launch_k8<W8, CT, 10, false>, &launch_k8<W8, CT, 10, true>}}; };   // [NWB 8 / 10][fused]
-static const K8Row<false, 1> kK8_16_1; static const K8Row<false, 2> kK8_16_2; static const K8Row<false, 4> kK8_16_4;
-static const K8Row<true, 1> kK8_8_1; static const K8Row<true, 2> kK8_8_2; static const K8Row<true, 4> kK8_8_4;
-static k8_launch_fn k8_fn(bool w8, int ct, int nwb, bool fused) {
-    const int i = nwb == 10, f = fused;
-    if (w8) return ct == 1 ? kK8_8_1.fn[i][f] : (ct == 2 ? kK8_8_2.fn[i][f] : kK8_8_4.fn[i][f]);
-    return ct == 1 ? kK8_16_1.fn[i][f] : (ct == 2 ? kK8_16_2.fn[i][f] : kK8_16_4.fn[i][f]);
-}
+using k8_launch_fn = int (*)(int dtype, GemvArgs a, int nrb, void* k8_part, hipStream_t s);
+static const k8_launch_fn kK8[2][3][2] = {      // [fp8 weights][column tiles 1 / 2 / 4][row blocks per workgroup 8 / 10]
+    {{&launch_k8<false, 1, 8>, &launch_k8<false, 1, 10>}, {&launch_k8<false, 2, 8>, &launch_k8<false, 2, 10>}, {&launch_k8<false, 4, 8>, &launch_k8<false, 4, 10>}},
+    {{&launch_k8<true, 1, 8>, &launch_k8<true, 1, 10>}, {&launch_k8<true, 2, 8>, &launch_k8<true, 2, 10>}, {&launch_k8<true, 4, 8>, &launch_k8<true, 4, 10>}}};
 
 // The 8-phase kernels stage up to 96 KB of x in dynamic LDS: the opt-in attribute is per function AND per device, so it is set for every
 // instantiation when a context is created on a device (pgv_ctx_create), never lazily inside a launch (which may sit in a graph capture).
-template <bool W8, int CT, int NWB, bool FUSED>
+template <bool W8, int CT, int NWB>
 static int configure_k8() {
-    PGV_HIP(hipFuncSetAttribute((const void*)gemv_k8_kernel<TF16, W8, CT, NWB, FUSED>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
-    PGV_HIP(hipFuncSetAttribute((const void*)gemv_k8_kernel<TBF16, W8, CT, NWB, FUSED>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
+    PGV_HIP(hipFuncSetAttribute((const void*)gemv_k8_kernel<TF16, W8, CT, NWB>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
+    PGV_HIP(hipFuncSetAttribute((const void*)gemv_k8_kernel<TBF16, W8, CT, NWB>, hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
     return PGV_OK;
 }
 template <bool W8, int CT>
-static int configure_k8_row() {
-    PGV_TRY((configure_k8<W8, CT, 8, false>())); PGV_TRY((configure_k8<W8, CT, 8, true>()));
-    PGV_TRY((configure_k8<W8, CT, 10, false>())); PGV_TRY((configure_k8<W8, CT, 10, true>()));
-    return PGV_OK;
-}
+static int configure_k8_row() { PGV_TRY((configure_k8<W8, CT, 8>())); PGV_TRY((configure_k8<W8, CT, 10>())); return PGV_OK; }
 int pgv_gemv_configure(pgv_ctx*) {
     PGV_TRY((configure_k8_row<false, 1>())); PGV_TRY((configure_k8_row<false, 2>())); PGV_TRY((configure_k8_row<false, 4>()));
     PGV_TRY((configure_k8_row<true, 1>())); PGV_TRY((configure_k8_row<true, 2>())); PGV_TRY((configure_k8_row<true, 4>()));
     return PGV_OK;
 }
 
-struct GemvChoice { int tl, ct; bool x2, k8; int nwb; bool fused; };
+struct GemvChoice { int tl, ct; bool x2, k8; int nwb; };
 
 // TL = row blocks per workgroup (they share the x fragments), CT = column tiles, x2 = merged x load, k8 = the 8-phase residual producer.
 static GemvChoice choose_gemv(int mode, bool w8, int B, int grid, int K, int num_cu, bool have_k8_scratch) {
-    GemvChoice c{1, B <= 16 ? 1 : (B <= 32 ? 2 : 4), B <= 8 && lab_switch("PGV_GEMV_X2", 1) != 0, false, 8, false};
+    GemvChoice c{1, B <= 16 ? 1 : (B <= 32 ? 2 : 4), B <= 8 && lab_switch("PGV_GEMV_X2", 1) != 0, false, 8};
     // row blocks (= waves) per 8-phase workgroup: 8, or 10 where that makes (row groups x 8 phases) exactly one workgroup per CU (13B: 320 row
     // blocks -> 32 groups x 8 = 256 workgroups of 10 waves instead of 320 of 8 = 1 1/4 rounds).  The (row block, phase) partition and the phase
     // order of the sums do not depend on it: bitwise the same result.
-    if (lab_switch("PGV_GEMV_K8_NWB10", K8_NWB10_DEFAULT) != 0 && grid % 10 == 0 && grid / 10 * 8 == num_cu) c.nwb = 10;
-    c.fused = lab_switch("PGV_GEMV_K8_FUSED", K8_FUSED_DEFAULT) != 0;
+    // (13B fp8, 8 sequences, same box: 6.53 -> 6.64 videos/s with down_proj alone in that shape, 6.71 with o_proj as well.)
+    if (lab_switch("PGV_GEMV_K8_NWB10", 1) != 0 && grid % 10 == 0 && grid / 10 * 8 == num_cu) c.nwb = 10;
     const bool k8_ok = have_k8_scratch && lab_switch("PGV_GEMV_K8", 1) != 0 && grid % c.nwb == 0;
     if (B > 16) {
         // Wide batches re-read 2 - 4 x the activation lines per workgroup, so the row blocks that share them matter more: qkv 3, gate/up two
@@ -727,7 +679,8 @@ static GemvChoice choose_gemv(int mode, bool w8, int B, int grid, int K, int num
         case GV_RESIDNORM:
             // fp8 down_proj of the 13B shapes (K = 13 824, 320 row blocks): a 16-row workgroup requests as many activation lines as weight lines
             // (LAB.md "what the activation operand costs"); the 8-phase form reads 1/8 of x per workgroup and is bitwise the same result
-            c.k8 = w8 && k8_ok && K >= lab_switch("PGV_GEMV_K8_NARROW_MINK", K8_NARROW_MINK_DEFAULT);
+            // With 10 row blocks per workgroup (13B) the short-K producer (o_proj, K = 5120) gains too: one workgroup per CU, 1/8 of x each.
+            c.k8 = w8 && k8_ok && K >= lab_switch("PGV_GEMV_K8_NARROW_MINK", c.nwb == 10 ? 4096 : 12288);
             break;
         default: break;
     }
@@ -757,10 +710,10 @@ int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void
     // W must be in the fragment-blocked layout with its row count padded to a multiple of 16 (zero rows)
     if (mode == GV_SWIGLU) { PGV_CHECK(N % 64 == 0, "gemv swiglu: N=%d must be a multiple of 64", N); grid = N / 32; }
     else { if (mode != GV_F32) PGV_CHECK(N % 16 == 0, "gemv: N=%d must be a multiple of 16", N); grid = (N + 15) / 16; }
-    const GemvChoice c = choose_gemv(mode, w8, B, grid, K, ctx->num_cu, norm && norm->k8_part && norm->k8_ticket);
+    const GemvChoice c = choose_gemv(mode, w8, B, grid, K, ctx->num_cu, norm && norm->k8_part);
     pgv_prof_begin(ctx, 3, s);
     if (c.k8) {
-        PGV_TRY(k8_fn(w8, c.ct, c.nwb, c.fused)(dtype, a, grid, norm->k8_part, norm->k8_ticket, s));
+        PGV_TRY(kK8[w8][c.ct == 1 ? 0 : (c.ct == 2 ? 1 : 2)][c.nwb == 10](dtype, a, grid, norm->k8_part, s));
     } else {
         const GemvShape* shape = nullptr;
         for (const GemvShape& g : kGemvShapes)

@@ -47,7 +47,6 @@ struct pgv_kv {
     float* amax_val; int* amax_idx;     // greedy candidates of the lm_head GEMV, tile-major: [ceil(B / 16)][vocab_cap / 16][16]
     float* ssq;                         // sum-of-squares partials of the folded RMSNorm, tile-major: [ceil(B / 16)][hidden / 16][16] (see GemvArgs in gemv.hip)
     int ssq_ts, amax_ts;                // their tile strides in elements: hidden, vocab_cap
-    unsigned* k8_ticket;                // ... arrival tickets of their fused finish, one per row group [hidden / 16 / 8] (zero between launches)
     void* k8_part;                      // 8-phase residual producers (gemv.hip gemv_k8_kernel): phase tiles [hidden / 16][8][column tiles][64] float4
     float* dattn_part; unsigned* dattn_ticket;   // context-split decode attention: partial states [B * heads][8][130], arrival tickets [B * heads] (zero between launches)
     int *d_pos, *d_cur, *d_step, *d_done, *d_hist;
@@ -280,7 +279,7 @@ extern "C" int pgv_kv_create(pgv_ctx* ctx, pgv_llm* llm, int batch, int max_seq,
     const size_t o_resid = take(B * H * 4), o_xn = take(B * H * 2), o_qkv = take(B * 3 * H * 2), o_ao = take(B * H * 2), o_act = take(B * I * 2),
                  o_logits = take(B * V * 4), o_ssq = take(CTn * H * 4), o_av = take(CTn * V * 4), o_ai = take(CTn * V * 4), o_ints = take((4 * B + B * (size_t)max_seq) * 4),
                  o_u = take(B * (size_t)max_seq * 4), o_dpart = take(B * llm->cfg.heads * (size_t)kDattnSplitMax * kDattnPart * 4), o_dtick = take(B * llm->cfg.heads * 4),
-                 o_k8 = take((H / 16) * 8 * CTn * 64 * 16), o_k8t = take((H / 16 / 8 + 1) * 4);
+                 o_k8 = take((H / 16) * 8 * CTn * 64 * 16);
     hipError_t e = hipMalloc((void**)&kv->blob, off);
     if (e != hipSuccess) { delete kv; pgv_set_error("pgv_kv_create: hipMalloc(%zu MiB): %s", off >> 20, hipGetErrorString(e)); return PGV_ENOMEM; }
     char* b = kv->blob;
@@ -290,10 +289,9 @@ extern "C" int pgv_kv_create(pgv_ctx* ctx, pgv_llm* llm, int batch, int max_seq,
     kv->d_pos = ints; kv->d_cur = ints + B; kv->d_step = ints + 2 * B; kv->d_done = ints + 3 * B; kv->d_hist = ints + 4 * B;
     kv->d_u = (float*)(b + o_u);
     kv->dattn_part = (float*)(b + o_dpart); kv->dattn_ticket = (unsigned*)(b + o_dtick);
-    kv->k8_part = (void*)(b + o_k8); kv->k8_ticket = (unsigned*)(b + o_k8t);
+    kv->k8_part = (void*)(b + o_k8);
     e = hipMemset(ints, 0, (4 * B + B * (size_t)max_seq) * 4);
     if (e == hipSuccess) e = hipMemset(kv->dattn_ticket, 0, B * llm->cfg.heads * 4);
-    if (e == hipSuccess) e = hipMemset(kv->k8_ticket, 0, (H / 16 / 8 + 1) * 4);
     if (e == hipSuccess) e = hipMemset(kv->ssq, 0, CTn * H * 4);
     kv->ssq_ts = (int)H; kv->amax_ts = (int)V;
     if (e != hipSuccess) { (void)hipFree(kv->blob); delete kv; pgv_set_error("pgv_kv_create: memset: %s", hipGetErrorString(e)); return PGV_EHIP; }
@@ -364,7 +362,6 @@ extern "C" int pgv_llm_prefill(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, const int32
     // arrival tickets of the context-split decode attention: a launch re-arms its own, but an ABORTED decode launch (device fault, process kill
     // between launches) would leave one non-zero for the next user of this cache -- every prefill starts from zeros
     PGV_HIP(hipMemsetAsync(kv->dattn_ticket, 0, (size_t)kv->B * heads * sizeof(unsigned), s));
-    PGV_HIP(hipMemsetAsync(kv->k8_ticket, 0, (size_t)(H / 16 / 8 + 1) * sizeof(unsigned), s));
     int M = 0, max_len = 0;
     for (int b = 0; b < B; ++b) {
         PGV_CHECK(h_seq_lens[b] >= 1 && h_seq_lens[b] <= kv->max_seq, "pgv_llm_prefill: sequence %d has %d tokens (cache holds %d)", b, h_seq_lens[b], kv->max_seq);
@@ -498,7 +495,7 @@ static int decode_enqueue(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int eos, int fla
         if (q8) PGV_TRY(gemv8(ctx, m, kv, GV_STORE16, l.q_wqkv, l.s_wqkv, kv->xn, H, kv->qkv, 3 * H, 3 * H, B, s, &cons));
         else PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_STORE16, l.wqkv, kv->xn, H, kv->qkv, 3 * H, 3 * H, H, B, s, nullptr, &cons));
         PGV_TRY(pgv_launch_decode_attn(ctx, m->dtype, kv->qkv, kv->d_pos, m->rope, kv->Kc[li], kv->Vc[li], kv->ao, B, H, heads, kv->max_seq, kv_bytes, s, kv->dattn_part, kv->dattn_ticket));
-        GemvNorm prod; prod.gamma = l.post_g; prod.xg = kv->xn; prod.ssq_out = kv->ssq; prod.ssq_ts = kv->ssq_ts; prod.k8_part = kv->k8_part; prod.k8_ticket = kv->k8_ticket;
+        GemvNorm prod; prod.gamma = l.post_g; prod.xg = kv->xn; prod.ssq_out = kv->ssq; prod.ssq_ts = kv->ssq_ts; prod.k8_part = kv->k8_part;
         if (q8) PGV_TRY(gemv8(ctx, m, kv, GV_RESIDNORM, l.q_wo, l.s_wo, kv->ao, H, kv->resid, H, H, B, s, &prod));
         else PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_RESIDNORM, l.wo, kv->ao, H, kv->resid, H, H, H, B, s, nullptr, &prod));
         cons.nparts_in = nparts;

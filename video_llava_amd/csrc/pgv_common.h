@@ -181,7 +181,6 @@ struct GemvNorm {
     const float* ssq_in = nullptr; int nparts_in = 0; int hidden = 1; float eps = 0.f;
     const float* gamma = nullptr; void* xg = nullptr; float* ssq_out = nullptr;
     float* amax_val = nullptr; int* amax_idx = nullptr;      // f32 mode: per-workgroup greedy candidates [ceil(N / 16)][16]
-    unsigned* k8_ticket = nullptr;                           // ... and its arrival tickets [N / 16 / 8] (zero between launches): the fused finish
     void* k8_part = nullptr;                                 // producer mode, batches beyond 16: scratch of the 8-phase form, [N / 16][8][B tiles][64] float4; null = 16-row kernel
     int ssq_ts = 0, amax_ts = 0;                             // batches beyond 16: the side arrays are tile-major [B / 16][...][16] with these tile strides (elements)
 };

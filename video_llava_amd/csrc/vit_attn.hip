@@ -44,17 +44,23 @@ struct AttnArgs {
 #define PGV_ATTN_ABL(p) 0          // the release library has no garbage-producing ablation switch (documented A/B switches: INTEGRATION.md)
 #endif
 
-// cross-half (lane l <-> l + 32) maximum with gfx950's half swap: one VALU op instead of a ds_bpermute round trip through the LDS crossbar.
-// Inline asm with two read-write operands: the builtin called with ONE value on both operands reads the second result from the wrong
-// register under hipcc 7.2 (gemv.hip rows_sum_to_row3).
+// cross-half (lane l <-> l + 32) maximum / sum with gfx950's half swap: one VALU op instead of a ds_bpermute round trip through the LDS crossbar.
+// v_permlane32_swap x, y exchanges x's upper half with y's lower half: lanes 0-31 end up with (own, partner's), lanes 32-63 with (partner's, own).
+// Inline asm, because the builtin cannot be used here: with one value on both operands hipcc 7.2 reads the second result from the wrong
+// register (gemv.hip rows_sum_to_row3), and with a second SSA copy of the value it folds max(r0, r1) to r0 (observed in the ISA).  The
+// `s_nop 1` is the wait state the compiler itself places between a VALU write of an operand and the swap (the first round-5 version had none:
+// wrong maxima at N = 5); nothing is needed behind it.
+__device__ __forceinline__ void half_swap(float& a, float& b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
 __device__ __forceinline__ float half_swap_max(float v) {
     float a = v, b = v;
-    asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));      // lanes 0-31: (own, partner's); lanes 32-63: (partner's, own)
+    half_swap(a, b);
     return fmaxf(a, b);
 }
 __device__ __forceinline__ float half_swap_sum(float v) {
     float a = v, b = v;
-    asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    half_swap(a, b);
     return a + b;
 }
 
