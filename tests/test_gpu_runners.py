@@ -319,29 +319,6 @@ def test_batched_runner_stops_on_a_text_stop_string(ctx, tmp_path):
     assert [x["tokens"] for x in lines] == [keep_n[n] for n in names]
 
 
-def test_generate_stop_string_ahead_of_eos_in_the_same_chunk(ctx):
-    """a direct `generate(stop_strings=...)` call at B = 1 whose chunk ends with the sequence at EOS must still cut at a stop string
-    that appears BEFORE that EOS in the same chunk (the per-token loop of the reference, model/utils.py:6-26, stops at the string first)."""
-    from video_llava_amd.inference import build_prompt
-    ccfg, lcfg, cw, lw, tower, model, ip, V = _tiny_components()
-    frames = synth.make_frames(5, ccfg.image, seed=60)
-    pooled = ovis.spatio_temporal_pool_torch(ovis.clip_select_features(ovis.clip_preprocess(frames), cw, ccfg)).half().to(DEV)[None]
-    prompt, _ = build_prompt("what happens 0?", "default", V, True)
-    ids = _Tok(lcfg.vocab)([prompt]).input_ids[0]
-    free = model.generate([ids], video_spatio_temporal_features=pooled, do_sample=False, max_new_tokens=40)[0, len(ids):].tolist()
-    first = [i for i in range(1, 30) if free[i] not in free[:i]]                           # positions >= 1 where a token occurs for the first time
-    assert len(first) >= 2, (free, "the free run has fewer than three distinct tokens in its first chunk: pick another clip / question")
-    i_stop, i_eos = first[0], first[1]                                                     # stop string first, a later fresh token plays EOS: both inside the first chunk of 32
-    tok = _StopTok(lcfg.vocab, {free[i_stop]})
-    out = model.generate([ids], video_spatio_temporal_features=pooled, do_sample=False, max_new_tokens=40, eos_token_id=free[i_eos],
-                         stop_strings=["###"], tokenizer=tok, chunk=32)
-    got = out[0, len(ids):].tolist()
-    assert got == free[:i_stop + 1], (got, free[:i_eos + 1], i_stop, i_eos)
-    # without a stop string the same call runs to the EOS
-    out = model.generate([ids], video_spatio_temporal_features=pooled, do_sample=False, max_new_tokens=40, eos_token_id=free[i_eos], chunk=32)
-    assert out[0, len(ids):].tolist() == free[:i_eos + 1]
-
-
 def test_runner_feature_cache_and_sampling_collation(ctx, tmp_path):
     """(a) Several questions about the same videos in different groups: the tower runs once per DISTINCT clip (LRU of pooled features across
     groups), and the predictions equal a run with the cache disabled.  (b) --do_sample goes through the same fixed-shape id collation as the

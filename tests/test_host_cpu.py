@@ -863,3 +863,54 @@ def test_runner_batch_auto_picks_the_widest_group_that_fits():
     assert p.parse_args([]).batch == "auto" and p.parse_args(["--batch", "16"]).batch == 16
     with pytest.raises(SystemExit):
         p.parse_args(["--batch", "65"])
+
+
+def test_generate_stop_string_ahead_of_eos_in_the_same_chunk():
+    """`generate(stop_strings=...)` at B = 1 whose chunk ends with the sequence at EOS must still cut at a stop string that appears
+    BEFORE that EOS in the same chunk (the reference's per-token loop, model/utils.py:6-26, stops at the string first).  Host logic only: the
+    device calls (prefill / decode_greedy) are scripted, so this runs without a GPU."""
+    import torch.nn as nn
+    from video_llava_amd.model.video_chatgpt import VideoChatGPTConfig, VideoChatGPTLlamaForCausalLM
+    script = [11, 12, 13, 14, 15, 16, 17, 18] + [19] * 60             # 14 decodes to the stop string, 16 plays EOS: both inside the first chunk of 32
+    STOP_ID, EOS = 14, 16
+
+    class Tok:
+        def __call__(self, text):                                     # "###" is not a single-id keyword: only the decoded-tail branch can see it
+            class R:
+                input_ids = [1, 40, 41, 42]
+            return R()
+
+        def batch_decode(self, ids, skip_special_tokens=True):
+            return [" ".join("###" if int(t) == STOP_ID else str(int(t)) for t in row) for row in ids]
+
+    def fake_model(eos):
+        m = object.__new__(VideoChatGPTLlamaForCausalLM)
+        nn.Module.__init__(m)
+        m.config = VideoChatGPTConfig(eos_token_id=eos)
+        m.device_ = torch.device("cpu")
+        cur = {"i": 0, "done": False}
+
+        def prefill(seqs, feats, max_seq, want_logits=False):
+            cur.update(i=1, done=script[0] == eos)
+            return None, torch.tensor([script[0]], dtype=torch.int32), None
+
+        def decode_greedy(kv, first, n, eos_id=-1):                   # the device loop: EOS is sticky (csrc/sampling.hip argmax_parts_kernel)
+            out = []
+            for _ in range(n):
+                t = eos_id if cur["done"] else script[cur["i"]]
+                cur["i"] += 1
+                cur["done"] = cur["done"] or (eos_id >= 0 and t == eos_id)
+                out.append(t)
+            return torch.tensor([out], dtype=torch.int32)
+        m.prefill, m.decode_greedy = prefill, decode_greedy
+        return m
+    ids = [1, 5, 6]
+    out = fake_model(EOS).generate([ids], max_new_tokens=40, stop_strings=["###"], tokenizer=Tok(), chunk=32)
+    assert out[0, len(ids):].tolist() == script[:4], out                # cut at the stop string (token 14), not at the EOS two tokens later
+    out = fake_model(EOS).generate([ids], max_new_tokens=40, chunk=32)  # without a stop string the same run ends at the EOS
+    assert out[0, len(ids):].tolist() == script[:6]
+    out = fake_model(None).generate([ids], max_new_tokens=40, stop_strings=["###"], tokenizer=Tok(), chunk=32, eos_token_id=None)
+    assert out[0, len(ids):].tolist() == script[:4]                     # no EOS at all: still one chunk, cut at the string
+    timings = {}
+    fake_model(EOS).generate([ids], max_new_tokens=40, stop_strings=["###"], tokenizer=Tok(), chunk=4, timings=timings)
+    assert timings["steps"] <= 8                                        # chunk of 4: the stop at token 4 ends the loop after the first chunk
