@@ -110,9 +110,12 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
     // (three independent loads whose first USE is after the weight loop: summing them here would park the wave on an L2 round trip
     // before its first weight load -- measured +1.4 us on the 18 us qkv GEMV)
     constexpr int SSQ_LD = 3;                                   // 3 x NW x 64 float4 >= 4 x hidden / 16 up to hidden 6144
+    // ... except in the widest shapes (4 row blocks x 4 column tiles): there the 48 registers the partials would occupy across the weight loop
+    // are what decides between 256 VGPRs and a spill, and a 60 us launch does not notice the round trip: requested after the loop.
+    constexpr bool SSQ_LATE = (CT * TILES >= 16);
     f32x4_t ssq_ld[CT][SSQ_LD];
     const bool scaled = (MODE == GV_STORE16 || MODE == GV_SWIGLU || MODE == GV_F32) && p.ssq_in != nullptr;
-    if (scaled) {
+    if (!SSQ_LATE && scaled) {
         const int n4 = p.nparts_in * 4;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
@@ -242,6 +245,13 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
     for (int t = 0; t < TILES; ++t)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) red[w][t * CT + ct][lane] = acc[t][ct];
+    if (SSQ_LATE && scaled) {
+        const int n4 = p.nparts_in * 4;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int q = 0; q < SSQ_LD; ++q) ssq_ld[ct][q] = ((const f32x4_t*)(p.ssq_in + (size_t)ct * p.ssq_ts))[min(tid + q * NW * 64, n4 - 1)];
+    }
     if (scaled) {
       const int n4 = p.nparts_in * 4;
 #pragma unroll
@@ -608,7 +618,7 @@ static const GemvShape kGemvShapes[] = {
     // 2 / 4 column tiles (B <= 32 / 64)
     gemv_shape<GV_STORE16, 1, 2>(), gemv_shape<GV_STORE16, 3, 2>(), gemv_shape<GV_RESID, 1, 2>(), gemv_shape<GV_SWIGLU, 2, 2>(), gemv_shape<GV_SWIGLU, 4, 2>(),
     gemv_shape<GV_F32, 1, 2>(), gemv_shape<GV_RESIDNORM, 1, 2>(),
-    gemv_shape<GV_STORE16, 1, 4>(), gemv_shape<GV_STORE16, 3, 4>(), gemv_shape<GV_RESID, 1, 4>(), gemv_shape<GV_SWIGLU, 2, 4>(),
+    gemv_shape<GV_STORE16, 1, 4>(), gemv_shape<GV_STORE16, 3, 4>(), gemv_shape<GV_RESID, 1, 4>(), gemv_shape<GV_SWIGLU, 2, 4>(), gemv_shape<GV_SWIGLU, 4, 4>(),
     gemv_shape<GV_F32, 1, 4>(), gemv_shape<GV_RESIDNORM, 1, 4>(),
 };
 
@@ -660,9 +670,10 @@ static GemvChoice choose_gemv(int mode, bool w8, int B, int grid, int K, int num
     const bool k8_ok = have_k8_scratch && lab_switch("PGV_GEMV_K8", 1) != 0 && grid % c.nwb == 0;
     if (B > 16) {
         // Wide batches re-read 2 - 4 x the activation lines per workgroup, so the row blocks that share them matter more: qkv 3, gate/up two
-        // (gate, up) pairs when the block counts divide (4 row blocks x 4 column tiles spill).
+        // (gate, up) pairs when the block counts divide.
         if (mode == GV_STORE16 && grid % 3 == 0) c.tl = 3;
-        if (mode == GV_SWIGLU) c.tl = (grid % 2 == 0 && B <= 32) ? 4 : 2;
+        // (four column tiles: 228 VGPRs once the sum-of-squares partials are requested after the weight loop, SSQ_LATE)
+        if (mode == GV_SWIGLU) c.tl = (grid % 2 == 0 && (B <= 32 || lab_switch("PGV_GEMV_WIDE_TL4", 1) != 0)) ? 4 : 2;
         // narrow matrices (o_proj, down_proj): 8 row blocks x K phase per workgroup + a finish launch where it pays (kernel trace at 32 clips:
         // down_proj 32.0 -> 22.4 + 4.9 us (finish), o_proj 13.3 -> 9.6 + 4.9: the short-K matrix only gains once the batch spans four tiles)
         if (mode == GV_RESIDNORM) c.k8 = k8_ok && (K / 64) >= 16 && (B > 32 || K >= 8192);
