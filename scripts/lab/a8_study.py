@@ -6,7 +6,7 @@ fp8 x fp8 MFMA (v_mfma_f32_16x16x32_fp8_fp8) needs the activation operand in e4m
 depth, what that does to the logits: the fp32 oracle of oracle/llm.py on the fp8-dequantised weights of the 13B full-depth case
 (oracle/fulldepth.py), once as is and once with the INPUT of every linear layer (q/k/v, o, gate/up, down, lm_head) rounded to e4m3 with a
 per-token power-of-two scale chosen from the exact amax (the most favourable activation quantiser a decode GEMV could implement).
-Usage: python oracle/a8_study.py [7b|13b] [n_new] [e4m3|hilo]"""
+Usage: python scripts/lab/a8_study.py [7b|13b] [n_new] [e4m3|hilo]   (the fp8 x fp8 path it priced was removed in round 5, ABI 300)"""
 from __future__ import annotations
 
 import os
@@ -15,7 +15,7 @@ import time
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import fulldepth as fd      # noqa: E402
 from oracle import llm as ollm          # noqa: E402
