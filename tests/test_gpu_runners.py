@@ -50,7 +50,7 @@ def test_extraction_loop_writes_reference_format(ctx, tmp_path):
         assert not got[T:100].any()
 
 
-def test_qa_runner_end_to_end_matches_oracle(ctx, tmp_path):
+def test_qa_runner_end_to_end_matches_oracle(ctx, tmp_path, capsys):
     from video_llava_amd.eval import run_inference_qa_activitynet as qa
     from video_llava_amd.inference import build_prompt
     from video_llava_amd.model.video_chatgpt import VideoChatGPTConfig, VideoChatGPTLlamaForCausalLM, VisionConfig
@@ -97,6 +97,16 @@ def test_qa_runner_end_to_end_matches_oracle(ctx, tmp_path):
         got = [int(t) for t in o["pred"].split()]
         assert min(margins) > 0.5, margins          # seeds (21, 22): every step's oracle margin is 0.9+ -- the comparison is never vacuous
         assert got == ref, (n, got, ref, margins)
+    # the runners' DEFAULT group size (`--batch auto`, round 5): picked from the GPU's free memory (64 on an MI355X next to this tiny model), and --
+    # batch invariance -- the same predictions as the explicit group size above
+    capsys.readouterr()
+    args2 = qa.parse_args(["--video_dir", str(vd), "--gt_file_question", str(tmp_path / "q.json"), "--gt_file_answers", str(tmp_path / "a.json"),
+                           "--output_dir", str(tmp_path / "out2"), "--output_name", "preds", "--model-name", "x", "--projection_path", "y",
+                           "--max_new_tokens", str(NEW)])
+    assert args2.batch == "auto"
+    out2 = qa.run_inference(args2, components=(model, tower, tok, IP(), V))
+    assert "--batch auto: 64 clips per group" in capsys.readouterr().out and args2.batch == 64
+    assert out2 == out
 
 
 def test_consistency_runner_end_to_end_matches_oracle(ctx, tmp_path):
