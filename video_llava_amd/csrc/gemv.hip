@@ -573,6 +573,8 @@ int pgv_launch_embed_tok_norm(int dtype, const int* tok, const void* embed, floa
 // ---------------------------------------------------------------------------------------------
 // Launch-shape A/B switches exist in the lab library only (-DPGV_LAB, never loaded by the product): PGV_GEMV_TL3, PGV_GEMV_X2, PGV_GEMV_K8,
 // PGV_GEMV_K8_NARROW_MINK.  The release library uses the defaults.
+constexpr int GEMV_TL4_DEFAULT = 0;      // round-5 experiment: flips once measured
+
 static int lab_switch(const char* name, int dflt) {
 #ifdef PGV_LAB
     const char* e = getenv(name);
@@ -613,7 +615,7 @@ constexpr GemvShape gemv_shape() {
 }
 static const GemvShape kGemvShapes[] = {
     // one MFMA tile of sequences (B <= 16)
-    gemv_shape<GV_STORE16, 1, 1>(), gemv_shape<GV_STORE16, 3, 1>(), gemv_shape<GV_RESID, 1, 1>(), gemv_shape<GV_SWIGLU, 2, 1>(),
+    gemv_shape<GV_STORE16, 1, 1>(), gemv_shape<GV_STORE16, 3, 1>(), gemv_shape<GV_STORE16, 4, 1>(), gemv_shape<GV_RESID, 1, 1>(), gemv_shape<GV_SWIGLU, 2, 1>(),
     gemv_shape<GV_F32, 1, 1>(), gemv_shape<GV_RESIDNORM, 1, 1>(),
     // 2 / 4 column tiles (B <= 32 / 64)
     gemv_shape<GV_STORE16, 1, 2>(), gemv_shape<GV_STORE16, 3, 2>(), gemv_shape<GV_RESID, 1, 2>(), gemv_shape<GV_SWIGLU, 2, 2>(), gemv_shape<GV_SWIGLU, 4, 2>(),
@@ -685,6 +687,10 @@ static GemvChoice choose_gemv(int mode, bool w8, int B, int grid, int K, int num
             // 13B: 960 -> 320 workgroups, two resident per CU -- with fp8 weights a 16-row workgroup requests as many activation lines as weight
             // lines: qkv 20.7 -> 18.7 us; with 16-bit weights the same launch shape LOSES 4 us per layer, so the relaxed bound is for fp8 only)
             if (lab_switch("PGV_GEMV_TL3", 1) != 0 && grid % 3 == 0 && grid / 3 <= (w8 ? 2 : 1) * num_cu && grid / 3 >= num_cu / 2) c.tl = 3;
+            // ... unless three blocks leave a ragged second round and FOUR give one round that nearly fills the chip (13B qkv: 960 row blocks ->
+            // 320 workgroups = 1 1/4 rounds with three, 240 workgroups on 256 CUs with four)
+            if (lab_switch("PGV_GEMV_TL4", GEMV_TL4_DEFAULT) != 0 && grid % 4 == 0 && grid / 4 <= num_cu && grid / 4 >= num_cu - num_cu / 8 &&
+                !(grid % 3 == 0 && grid / 3 == num_cu)) c.tl = 4;
             break;
         case GV_SWIGLU: c.tl = 2; break;
         case GV_RESIDNORM:
