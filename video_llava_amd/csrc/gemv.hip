@@ -573,8 +573,6 @@ int pgv_launch_embed_tok_norm(int dtype, const int* tok, const void* embed, floa
 // ---------------------------------------------------------------------------------------------
 // Launch-shape A/B switches exist in the lab library only (-DPGV_LAB, never loaded by the product): PGV_GEMV_TL3, PGV_GEMV_X2, PGV_GEMV_K8,
 // PGV_GEMV_K8_NARROW_MINK.  The release library uses the defaults.
-constexpr int GEMV_TL4_DEFAULT = 0;      // round-5 experiment: flips once measured
-
 static int lab_switch(const char* name, int dflt) {
 #ifdef PGV_LAB
     const char* e = getenv(name);
@@ -688,8 +686,9 @@ static GemvChoice choose_gemv(int mode, bool w8, int B, int grid, int K, int num
             // lines: qkv 20.7 -> 18.7 us; with 16-bit weights the same launch shape LOSES 4 us per layer, so the relaxed bound is for fp8 only)
             if (lab_switch("PGV_GEMV_TL3", 1) != 0 && grid % 3 == 0 && grid / 3 <= (w8 ? 2 : 1) * num_cu && grid / 3 >= num_cu / 2) c.tl = 3;
             // ... unless three blocks leave a ragged second round and FOUR give one round that nearly fills the chip (13B qkv: 960 row blocks ->
-            // 320 workgroups = 1 1/4 rounds with three, 240 workgroups on 256 CUs with four)
-            if (lab_switch("PGV_GEMV_TL4", GEMV_TL4_DEFAULT) != 0 && grid % 4 == 0 && grid / 4 <= num_cu && grid / 4 >= num_cu - num_cu / 8 &&
+            // 320 workgroups = 1 1/4 rounds with three, 240 workgroups on 256 CUs with four: same box, fp8 weights 6.68 -> 6.92 videos/s and the
+            // GEMV family 0.539 -> 0.570 of 8 TB/s; 16-bit weights 4.79 -> 4.84)
+            if (lab_switch("PGV_GEMV_TL4", 1) != 0 && grid % 4 == 0 && grid / 4 <= num_cu && grid / 4 >= num_cu - num_cu / 8 &&
                 !(grid % 3 == 0 && grid / 3 == num_cu)) c.tl = 4;
             break;
         case GV_SWIGLU: c.tl = 2; break;
