@@ -914,3 +914,55 @@ def test_generate_stop_string_ahead_of_eos_in_the_same_chunk():
     timings = {}
     fake_model(EOS).generate([ids], max_new_tokens=40, stop_strings=["###"], tokenizer=Tok(), chunk=4, timings=timings)
     assert timings["steps"] <= 8                                        # chunk of 4: the stop at token 4 ends the loop after the first chunk
+
+
+def test_generate_chunk_bookkeeping_per_sequence():
+    """The per-chunk token bookkeeping of generate() (vectorised per sequence in round 5): every sequence keeps its tokens up to and including
+    its first EOS, finished sequences ignore later chunks, the loop ends with the chunk in which the last sequence finishes, `steps` counts up
+    to that token.  Scripted device calls (no GPU): three sequences whose EOS falls in the first chunk, in the second chunk, never / late."""
+    import torch.nn as nn
+    from video_llava_amd.model.video_chatgpt import VideoChatGPTConfig, VideoChatGPTLlamaForCausalLM
+    EOS = 9
+
+    def run(eos_at, max_new, chunk):
+        B = len(eos_at)
+        scripts = [[100 * (b + 1) + i for i in range(200)] for b in range(B)]
+        for b, k in enumerate(eos_at):
+            if k is not None:
+                scripts[b][k] = EOS
+        m = object.__new__(VideoChatGPTLlamaForCausalLM)
+        nn.Module.__init__(m)
+        m.config = VideoChatGPTConfig(eos_token_id=EOS)
+        m.device_ = torch.device("cpu")
+        st = {"i": 0, "done": [False] * B, "calls": 0}
+
+        def prefill(seqs, feats, max_seq, want_logits=False):
+            st["i"] = 1
+            st["done"] = [scripts[b][0] == EOS for b in range(B)]
+            return None, torch.tensor([scripts[b][0] for b in range(B)], dtype=torch.int32), None
+
+        def decode_greedy(kv, first, n, eos_id=-1):
+            st["calls"] += 1
+            out = [[0] * n for _ in range(B)]
+            for j in range(n):
+                for b in range(B):
+                    t = eos_id if st["done"][b] else scripts[b][st["i"]]
+                    st["done"][b] = st["done"][b] or t == eos_id
+                    out[b][j] = t
+                st["i"] += 1
+            return torch.tensor(out, dtype=torch.int32)
+        m.prefill, m.decode_greedy = prefill, decode_greedy
+        tm = {}
+        out = m.generate([[1, 2, 3]] * B, max_new_tokens=max_new, chunk=chunk, timings=tm)
+        return out[:, 3:].tolist(), tm["steps"], st["calls"], scripts
+
+    rows, steps, calls, sc = run([2, 40, None], 50, 32)
+    assert steps == 50 and calls == 2                                             # 1 + 32 + 17 tokens
+    assert rows[0][:3] == sc[0][:3] and rows[0][3:] == [EOS] * 47                  # finished at its EOS, padded with EOS
+    assert rows[1][:41] == sc[1][:41] and rows[1][41:] == [EOS] * 9
+    assert rows[2] == sc[2][:50]
+    rows, steps, calls, sc = run([2, 40, 45], 120, 32)
+    assert steps == 46 and calls == 2 and len(rows[0]) == 46                      # ends with the chunk in which the last sequence finished; steps up to its EOS
+    assert rows[2] == sc[2][:46] and rows[1] == sc[1][:41] + [EOS] * 5
+    rows, steps, calls, sc = run([0, 0], 20, 8)
+    assert steps == 1 and calls == 0 and rows == [[EOS], [EOS]]                   # both finished by the prefill's token
