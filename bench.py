@@ -32,6 +32,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The CPUs this process may use as it was STARTED: main() narrows the mask to the rank's share of its GPU's NUMA node (parallel.pin_rank_to_numa_node);
+# the CPU-baseline child is placed from the original mask (one hardware thread per physical core of one node), not from the rank's slice.
+ORIG_AFFINITY = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
 
 PEAK_MFMA_TFLOPS = 2500.0     # dense bf16/fp16, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0         # HBM3E spec, MI355X_MICROARCH.md
@@ -274,7 +277,7 @@ def _numa_node_cpus():
             for part in open(os.path.join(path, "cpulist")).read().strip().split(","):
                 lo, _, hi = part.partition("-")
                 cpus += list(range(int(lo), int(hi or lo) + 1))
-            allowed = os.sched_getaffinity(0)
+            allowed = ORIG_AFFINITY if ORIG_AFFINITY is not None else os.sched_getaffinity(0)
             phys = []
             for c in cpus:
                 if c not in allowed:

@@ -144,8 +144,9 @@ def pin_rank_to_numa_node(local_rank: int, n_local: int | None = None, sysfs_roo
         torch.set_num_threads(threads)
         if not _pin_logged and not quiet:
             _pin_logged = True
+            import sys
             print(f"[pgv] local rank {local_rank}: GPU {bdf} on NUMA node {mine} ({peers.index(bdf) + 1} of {len(peers)} GPUs there) -> CPUs "
-                  f"{share[0]}-{share[-1]} ({len(share)}), {threads} ATen threads (PGV_RANK_AFFINITY=0 disables)", flush=True)
+                  f"{share[0]}-{share[-1]} ({len(share)}), {threads} ATen threads (PGV_RANK_AFFINITY=0 disables)", file=sys.stderr, flush=True)     # stderr: bench.py's stdout is ONE JSON line
         return share
     except Exception:                                            # noqa: BLE001
         return None
