@@ -178,8 +178,11 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_kernel(const typename T::
 constexpr int DSPLIT_MAX = 8;
 constexpr int DPART = HD + 2;                            // floats per partial state: o[128] (unnormalised, relative to m), m, l
 
+#ifndef PGV_LAB_DATTN_WAVES_PER_EU
+#define PGV_LAB_DATTN_WAVES_PER_EU 6      // lab A/B: -DPGV_LAB_DATTN_WAVES_PER_EU=5 restores two workgroups per CU
+#endif
 template <typename T, int SPLIT>
-__global__ __launch_bounds__(512) void decode_attn_split_kernel(const typename T::elem* __restrict__ qkv, const int* __restrict__ pos_arr,
+__global__ __launch_bounds__(512, PGV_LAB_DATTN_WAVES_PER_EU) void decode_attn_split_kernel(const typename T::elem* __restrict__ qkv, const int* __restrict__ pos_arr,
                                                                 const float2* __restrict__ rope, typename T::elem* __restrict__ Kc,
                                                                 typename T::elem* __restrict__ Vc, typename T::elem* __restrict__ out, int H, int heads,
                                                                 int max_seq, float scale_log2e, float* __restrict__ part, unsigned* __restrict__ ticket) {
@@ -242,20 +245,7 @@ __global__ __launch_bounds__(512) void decode_attn_split_kernel(const typename T
             for (int e = 0; e < 8; ++e) o[u][e] = o[u][e] * alpha + pv * (float)vf[e];
         }
     };
-    // fresh token: split 0, wave 0 appends the rotated k and v to the cache and feeds them to the softmax from registers
-    typename T::v8 knew, vnew;
     const bool fresh = (sp == 0 && w == 0);
-    if (fresh) {
-        float kr[8];
-        rotate(*(const typename T::v8*)(k + dc * 8), *(const typename T::v8*)(k + (dc ^ 8) * 8), kr);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) knew[e] = T::from_f32(kr[e]);
-        vnew = *(const typename T::v8*)(v + dc * 8);
-        if (slot == 0) {
-            *(typename T::v8*)(kcache + (size_t)pos * HD + dc * 8) = knew;
-            *(typename T::v8*)(vcache + (size_t)pos * HD + dc * 8) = vnew;
-        }
-    }
     for (int r0 = 0; 16 * (SPLIT * 4 * r0 + sp) < n_keys; r0 += DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
@@ -265,7 +255,27 @@ __global__ __launch_bounds__(512) void decode_attn_split_kernel(const typename T
             for (int u = 0; u < 2; ++u) load_row(max(0, min(key_of(r0 + d + DEPTH, u), n_keys - 1)), kq[d][u], vq[d][u]);     // clamped rows are masked
         }
     }
-    if (fresh) update(0, knew, vnew, slot == 0);
+    // fresh token: split 0, wave 0 appends the rotated k and v to the cache and feeds them to the softmax from registers -- AFTER the key loop
+    // (round 5), when the ring of prefetched keys is dead: rotating k up front kept 96 VGPRs live, 5 waves per SIMD = two workgroups per CU, so
+    // 13B's 640 workgroups ran as 512 + 128; with the block here the kernel fits 80 VGPRs = three workgroups per CU, all 640 resident at once.
+    // Same values in the same order (the fresh key always entered the softmax last): bitwise the former result.
+    if (fresh) {
+        typename T::v8 knew, vnew;
+        float cs_c[8], cs_s[8], kr[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float2 cs = rope[(size_t)pos * 64 + j0 + e]; cs_c[e] = cs.x; cs_s[e] = dc < 8 ? -cs.y : cs.y; }
+        const typename T::v8 k_own = *(const typename T::v8*)(k + dc * 8), k_oth = *(const typename T::v8*)(k + (dc ^ 8) * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) kr[e] = (float)T::from_f32((float)k_own[e] * cs_c[e] + (float)k_oth[e] * cs_s[e]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) knew[e] = T::from_f32(kr[e]);
+        vnew = *(const typename T::v8*)(v + dc * 8);
+        if (slot == 0) {
+            *(typename T::v8*)(kcache + (size_t)pos * HD + dc * 8) = knew;
+            *(typename T::v8*)(vcache + (size_t)pos * HD + dc * 8) = vnew;
+        }
+        update(0, knew, vnew, slot == 0);
+    }
     auto combine = [&](float& ma, float& la, float (&oa)[8], float mb, float lb, const float (&ob)[8]) {
         const float mn = fmaxf(ma, mb);
         const float fa = exp2f(ma - mn), fb = exp2f(mb - mn);
