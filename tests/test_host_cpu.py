@@ -385,6 +385,7 @@ def test_no_kernel_spills_to_scratch():
     import tempfile
     checked = 0
     bad = []
+    regs = {}
     with tempfile.TemporaryDirectory() as td:
         for src in build.sources_present():
             obj = os.path.join(build.OBJ, src.replace(".hip", ".o"))
@@ -399,12 +400,25 @@ def test_no_kernel_spills_to_scratch():
             names = re.findall(r"\.name:\s+(\S+)", notes)
             segs = [int(x) for x in re.findall(r"\.private_segment_fixed_size:\s+(\d+)", notes)]
             spills = [int(x) for x in re.findall(r"\.vgpr_spill_count:\s+(\d+)", notes)]
-            assert len(names) == len(segs) == len(spills), src
+            vgprs = [int(x) for x in re.findall(r"\.vgpr_count:\s+(\d+)", notes)]
+            assert len(names) == len(segs) == len(spills) == len(vgprs), src
             checked += len(names)
             bad += [(n, sg, v) for n, sg, v in zip(names, segs, spills) if v > 0]
+            regs.update(zip(names, vgprs))
             os.remove(fat)
     assert checked >= 20, f"only {checked} kernels found"
     assert not bad, f"kernels spilling VGPRs: {bad[:6]}"
+    # Register budgets the launch shapes rely on (gfx950: 512 VGPRs per SIMD lane): a kernel that grows past its budget silently halves its
+    # occupancy -- two waves per SIMD for the ViT attention (256), three workgroups of 8 waves per CU for the split decode attention (80:
+    # all 640 workgroups of a 13B launch resident), one workgroup per CU with two waves per SIMD for the widest GEMV shapes (256).
+    def worst(fragment):
+        hit = {n: v for n, v in regs.items() if fragment in n}
+        assert hit, fragment
+        return max(hit.values())
+    assert worst("vit_attn_kernel") <= 256
+    assert worst("decode_attn_split_kernel") <= 80
+    assert worst("decode_attn_kernelI") <= 128
+    assert worst("gemv_mfma_kernel") <= 256 and worst("gemv_k8_kernel") <= 168
 
 
 def test_gemm_tile_order_is_a_bijection(tmp_path):
