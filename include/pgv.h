@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PGV_VERSION 300
+#define PGV_VERSION 310
 
 enum { PGV_OK = 0, PGV_EINVAL = 1, PGV_EHIP = 2, PGV_ENOMEM = 3, PGV_ESTATE = 4, PGV_ENAME = 5 };
 enum { PGV_F16 = 0, PGV_BF16 = 1, PGV_F32 = 2 };
@@ -176,6 +176,21 @@ void pgv_kv_destroy(pgv_kv *kv);
 int pgv_llm_prefill(pgv_ctx *ctx, pgv_llm *llm, pgv_kv *kv, const int32_t *h_ids, const int32_t *h_seq_lens, int B,
                     const void *d_video, int V, const int32_t *h_vid_pos, float *d_logits, int32_t *d_next, float *d_all_logits,
                     int ld_all, void *stream);
+
+/* Prefill of NEW tokens behind the ones already in the cache: VideoChatGPTLlamaForCausalLM.forward called with `past_key_values` and
+ * input_ids.shape[1] > 1 (video_chatgpt/model/video_chatgpt.py:193-251 accepts any input_ids next to a cache; :103 still splices when the new
+ * ids carry a placeholder run) -- what a second chat turn is (video_chatgpt/chat.py:108-160 re-tokenises and re-runs the WHOLE conversation
+ * every turn although the prefix is unchanged).  Same arguments as pgv_llm_prefill; B must equal the batch of the prefill that filled `kv`;
+ * row p of sequence b takes position pgv_kv_len(kv, b) + p, attends to the cached prefix and the new rows before it, and is appended.
+ * h_vid_pos is relative to the NEW rows.  Outputs as pgv_llm_prefill (d_all_logits: the new rows only).  An appended row is bitwise the row
+ * one full prefill over prefix + new tokens computes. */
+int pgv_llm_prefill_append(pgv_ctx *ctx, pgv_llm *llm, pgv_kv *kv, const int32_t *h_ids, const int32_t *h_seq_lens, int B,
+                           const void *d_video, int V, const int32_t *h_vid_pos, float *d_logits, int32_t *d_next, float *d_all_logits,
+                           int ld_all, void *stream);
+/* Forget the cache entries of sequence b from position `len` on (1 <= len <= pgv_kv_len): the next append / decode call continues there.
+ * Used when a new chat turn shares only a prefix with what the cache holds (surplus decode steps past a stop string,
+ * video_chatgpt/model/utils.py:6-26). */
+int pgv_kv_truncate(pgv_kv *kv, int b, int len, void *stream);
 
 /* One decode step for all B sequences (the `input_ids.shape[1] == 1` branch, :103): consumes
  * d_last [B] token ids, appends to the KV cache, writes d_logits [B, vocab] and/or d_next [B]. */

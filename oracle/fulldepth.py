@@ -57,13 +57,13 @@ def teacher_tokens(cfg: synth.LlamaCfg, prompt_seed: int, n: int):
     return np.random.default_rng([4321, prompt_seed]).integers(3, 32000, n).tolist()
 
 
-def teacher_forced_reference(w: dict, cfg: synth.LlamaCfg, ids, feats, cont):
+def teacher_forced_reference(w: dict, cfg: synth.LlamaCfg, ids, feats, cont, cache_weights: bool = False):
     """fp32 oracle logits at the len(cont) + 1 positions a teacher-forced decode visits, in ONE causal pass over ids + cont
     (position S-1+i predicts the token after ids + cont[:i]) -> (logits [n+1, vocab], margins [n+1], argmax [n+1]).  One pass instead
     of n sequential steps: a 32-layer fp32 forward over ~540 tokens costs about what the 441-token prefill costs."""
     PATCH, START, END = cfg.vocab - 3, cfg.vocab - 2, cfg.vocab - 1
     with torch.no_grad():
-        lg = ollm.LlamaOracle(w, cfg).prefill(list(ids) + list(cont), feats, START, END, PATCH, all_logits=True)[len(ids) - 1:]
+        lg = ollm.LlamaOracle(w, cfg, cache_weights=cache_weights).prefill(list(ids) + list(cont), feats, START, END, PATCH, all_logits=len(cont) + 1)
     top2 = torch.topk(lg, 2, dim=-1)
     return lg, (top2.values[:, 0] - top2.values[:, 1]).tolist(), top2.indices[:, 0].tolist()
 

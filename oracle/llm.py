@@ -145,14 +145,18 @@ class LlamaOracle:
             x = self._layer(i, x, cos, sin)
         self.pos += S
         x = rms_norm(x, _t(w, "model.norm.weight", dt), cfg.eps)
-        if not all_logits:
+        if all_logits is True:
+            pass
+        elif all_logits:                                   # an int n: the last n positions only (a long causal pass judged at its tail)
+            x = x[-int(all_logits):]
+        else:
             x = x[-1:]
         return x @ _t(w, "lm_head.weight", dt).t()
 
     def prefill(self, input_ids, video_feats: torch.Tensor | None, vid_start: int, vid_end: int,
                 vid_patch: int, all_logits: bool = False) -> torch.Tensor:
         """input_ids [S] ints; video_feats [V, 1024] pooled CLIP features or None.
-        Returns logits [1, vocab] for the last position (or [S, vocab])."""
+        Returns logits [1, vocab] for the last position (all_logits=True: [S, vocab]; all_logits=n: the last n positions)."""
         ids = torch.as_tensor(input_ids, dtype=torch.long)
         x = _t(self.w, "model.embed_tokens.weight", self.dtype)[ids]
         if video_feats is not None and ids.shape[0] != 1:

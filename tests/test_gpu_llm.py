@@ -62,12 +62,89 @@ def test_forward_is_callable_like_the_reference(ctx, golden_dir, tag, proj, imag
     # what has no counterpart in the eval path fails loudly
     with pytest.raises(NotImplementedError):
         m(input_ids=torch.tensor([ids]), labels=torch.tensor([ids]))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError, match="sequences for a cache"):
         m(input_ids=torch.tensor([ids[:3]]), past_key_values=out2.past_key_values)
+    with pytest.raises(RuntimeError, match="stale"):          # `out`'s cache was refilled by the batch-2 prefill above
+        m(input_ids=tok, past_key_values=out.past_key_values)
     with pytest.raises(RuntimeError, match="stale"):
-        stale = out.past_key_values
+        stale = out2.past_key_values
         m.generate(torch.tensor([ids]), video_spatio_temporal_features=feats, max_new_tokens=2, eos_token_id=None)
-        m(input_ids=tok, past_key_values=stale)
+        m(input_ids=torch.tensor([[5], [6]]), past_key_values=stale)
+
+
+def test_forward_stale_cache_of_the_same_shape_is_refused(ctx):
+    """one KV cache is kept alive per model and a second prefill of the SAME (batch, capacity) refills it in place -- the first
+    call's past_key_values then describes a cache that no longer holds its tokens.  The handle is the same object, so only the epoch tells."""
+    cfg = synth.LLAMA_TINY
+    m = _model(cfg, synth.make_llama_weights(cfg, seed=3, head_std=0.08), torch.float16)
+    a = m(input_ids=torch.tensor([[1, 7, 8, 9]]))
+    b = m(input_ids=torch.tensor([[1, 20, 21, 22]]))
+    assert a.past_key_values.kv is b.past_key_values.kv            # same shape -> same cache, refilled
+    with pytest.raises(RuntimeError, match="stale"):
+        m(input_ids=torch.tensor([[5]]), past_key_values=a.past_key_values)
+    nxt = m(input_ids=torch.tensor([[5]]), past_key_values=b.past_key_values)        # the live one still steps
+    ref = m(input_ids=torch.tensor([[1, 20, 21, 22, 5]]))
+    assert torch.equal(nxt.logits[0, 0], ref.logits[0, -1]) or rel(nxt.logits[0, 0], ref.logits[0, -1]) < 1e-3
+    # capacity follows the prompt (+ 256 positions, rounded to 64), not the whole context window; max_length overrides
+    assert ref.past_key_values.max_seq == 320 and m(input_ids=torch.tensor([[1, 2]]), max_length=1000).past_key_values.max_seq == 1024
+    small = m(input_ids=torch.tensor([[1, 2, 3]]), max_length=4)
+    m(input_ids=torch.tensor([[4]]), past_key_values=small.past_key_values)
+    assert small.past_key_values.max_seq == 64                     # rounded up to 64 positions
+    with pytest.raises(ValueError, match="exceed the cache"):
+        m(input_ids=torch.tensor([list(range(3, 3 + 61))]), past_key_values=small.past_key_values)
+
+
+@pytest.mark.parametrize("tag,proj,image", [("lin", "linear", 224), ("mlp", "mlp2x_gelu", 336)])
+def test_forward_with_cache_appends_many_tokens_bitwise(ctx, golden_dir, tag, proj, image):
+    """VERDICT r5 missing #4: `model(input_ids [B, S > 1], past_key_values=...)` (video_chatgpt/model/video_chatgpt.py:193-251 accepts any input_ids
+    next to a cache; a later chat turn) -> pgv_llm_prefill_append.  The prompt of the reference-generated fixture cut into 2 and 3 calls at
+    several points -- before the video run (the splice then happens inside the APPEND call), inside the text behind it, one token before the
+    end -- gives, row for row, BITWISE the logits of the one-call forward (which is checked against the reference's own output), and the
+    greedy continuation reproduces the fixture's tokens."""
+    g = np.load(os.path.join(golden_dir, "llama_tiny.npz"))
+    cfg = synth.LlamaCfg(**{**synth.LLAMA_TINY.__dict__, "projector": proj})
+    w = synth.make_llama_weights(cfg, seed=int(g[tag + "_weight_seed"]), head_std=float(g["head_std"]))
+    m = _model(cfg, w, torch.float16, image)
+    ids = g[tag + "_ids"].tolist()
+    S = len(ids)
+    feats = torch.from_numpy(g[tag + "_feats"]).half()[None]
+    toks_ref = g[tag + "_tokens"].tolist()
+    full = m(input_ids=torch.tensor([ids]), video_spatio_temporal_features=feats).logits[0].clone()
+    assert rel(full, torch.from_numpy(g[tag + "_prefill_logits"])) < 1e-3
+    start = ids.index(cfg.vocab - 2)                                # <vid_start>
+    end = ids.index(cfg.vocab - 1)                                  # <vid_end>
+    for cuts in ((start,), (2,), (end + 1,), (end + 3,), (S - 1,), (2, end + 2), (start, end + 1, S - 2)):
+        bounds = [0, *cuts, S]
+        out, rows = None, []
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            out = m(input_ids=torch.tensor([ids[a:b]]), video_spatio_temporal_features=feats, past_key_values=None if out is None else out.past_key_values,
+                    max_length=S + 16)
+            assert tuple(out.logits.shape) == (1, b - a, cfg.vocab) and out.past_key_values.get_seq_length() == b
+            rows.append(out.logits[0].clone())
+        assert torch.equal(torch.cat(rows), full), (cuts, rel(torch.cat(rows), full))
+        tok = out.logits[:, -1].argmax(-1, keepdim=True)
+        got = [int(tok[0, 0])]
+        for _ in range(1, len(toks_ref)):
+            out = m(input_ids=tok, past_key_values=out.past_key_values)
+            tok = out.logits[:, -1].argmax(-1, keepdim=True)
+            got.append(int(tok[0, 0]))
+        assert got == toks_ref, cuts
+    # a cut INSIDE the placeholder run cannot be spliced: the reference's own error (model/video_chatgpt.py:128)
+    out = m(input_ids=torch.tensor([ids[:start + 3]]), max_length=S + 16)
+    with pytest.raises(ValueError, match="video start tokens and video end tokens should be the same"):
+        m(input_ids=torch.tensor([ids[start + 3:]]), video_spatio_temporal_features=feats, past_key_values=out.past_key_values)
+    # ragged batch through the low-level call: two sequences with different prefixes and different appended lengths == their single runs
+    A, Bq = ids, ids[:end + 2] + [7, 8, 9, 10, 11]
+    kv, _n, _l = m.prefill([A[:end + 1], Bq[:start]], torch.cat([feats, feats]), S + 32)
+    _kv, nxt2, lg2 = m.prefill([A[end + 1:], Bq[start:]], torch.cat([feats, feats]), 0, want_logits=True, append_to=kv)
+    assert [m.ctx.lib.pgv_kv_len(kv, b) for b in range(2)] == [len(A), len(Bq)]
+    with pytest.raises(RuntimeError, match="holds 2 prefilled"):
+        m.prefill([[3]], None, 0, append_to=kv)
+    for b, seq in enumerate((A, Bq)):
+        _k, n1, l1 = m.prefill([seq], feats, S + 32, want_logits=True)
+        assert torch.equal(l1[0], lg2[b]) and int(n1[0]) == int(nxt2[b]), b
+
+
 
 
 @pytest.mark.parametrize("tag,proj,image", [("lin", "linear", 224), ("mlp", "mlp2x_gelu", 336)])
@@ -237,6 +314,64 @@ def test_7b_shaped_two_layers_vs_oracle(ctx, dtype, tol, shape):
     print(f"{shape}-shaped 2-layer oracle margins ({dtype}): {[round(x, 3) for x in margins]}")
     assert min(margins) > 0.3, margins                       # > 5 sigma of the bf16 logit noise at this width (0.06), ~70 sigma in fp16
     assert toks == toks_ref, (toks, toks_ref, margins)       # token-exact in fp16 AND bf16
+
+
+@pytest.mark.parametrize("shape", ["7b", "13b"])
+def test_context_horizon_4096_two_layers_vs_oracle(ctx, shape):
+    """VERDICT r5 #1b: kMaxPos.  A 2-layer 7B-shaped model (unsplit decode attention) and a 2-layer 13B-shaped one (40 heads: the context-split
+    attention with its fence-free merge) decode to the LAST position the cache can hold, 4095 (max_position_embeddings of Vicuna-1.5 / LLaVA-1.5 =
+    kMaxPos in csrc/llm.hip; the reference's default run ends at 1475 / 1795): `generate()` free-runs from a 441-token prompt until the cache is
+    full (3655 tokens through the hipGraph loop), the same tokens are then fed one by one through decode_step and the logits of the last 64
+    positions (4032 .. 4095) are compared with ONE causal fp32 oracle pass over all 4096 tokens (RoPE angles, the key loop and the split merge
+    at full length); the stepwise argmax there equals what generate() emitted.  One token more is refused."""
+    dtype = torch.float16
+    cfg = synth.LlamaCfg(layers=2) if shape == "7b" else synth.LlamaCfg(layers=2, hidden=5120, inter=13824, heads=40)
+    w = synth.quantize_weights(synth.make_llama_weights(cfg, seed=TWO_LAYER_SEED[shape], head_std=0.05), "float16")
+    m = _model(cfg, w, dtype)
+    rng = np.random.default_rng(1)
+    PATCH, START, END = cfg.vocab - 3, cfg.vocab - 2, cfg.vocab - 1
+    V, T, TAIL = 356, 4096, 64
+    ids = [1] + rng.integers(3, 32000, 70).tolist() + [START] + [PATCH] * V + [END] + rng.integers(3, 32000, 12).tolist()
+    S = len(ids)
+    feats = torch.from_numpy(rng.standard_normal((V, 1024), dtype=np.float32) * 2).to(dtype)
+    with pytest.raises(ValueError, match="exceeds max_position_embeddings"):
+        m.generate(torch.tensor([ids]), video_spatio_temporal_features=feats[None], do_sample=False, max_new_tokens=T - S + 1)
+    out = m.generate(torch.tensor([ids]), video_spatio_temporal_features=feats[None], do_sample=False, max_new_tokens=T - S, chunk=256)
+    gen = out[0, S:].tolist()
+    assert len(gen) == T - S and out.shape[1] == T
+    # stepwise over the same tokens: gen[i] is fed at position S + i; the step that feeds gen[T - S - 2] writes position 4094 ... the cache
+    # holds prompt + gen[:-1] = 4095 entries afterwards; one more step (feeding gen[-1] at position 4095) fills it
+    kv, nxt, lg = m.prefill([ids], feats, T, want_logits=True)
+    assert int(nxt[0]) == gen[0]
+    gen_dev = torch.tensor(gen, dtype=torch.int32, device=DEV)
+    L, picks = [], []
+    for i in range(T - S):
+        want = i >= T - S - TAIL
+        nxt, lg = m.decode_step(kv, gen_dev[i:i + 1], want_logits=want)
+        if want:
+            L.append(lg[0].clone()); picks.append(int(nxt[0]))
+    assert m.ctx.lib.pgv_kv_len(kv, 0) == T
+    with pytest.raises(ValueError, match="cache holds"):
+        m.decode_step(kv, gen_dev[:1])
+    L = torch.stack(L).float().cpu()                                # logits after feeding positions 4032 .. 4095
+    import time
+    t0 = time.time()
+    with torch.no_grad():
+        lg_ref = ollm.LlamaOracle(w, cfg).prefill(ids + gen, feats.float(), START, END, PATCH, all_logits=TAIL)
+    errs = [rel(L[i], lg_ref[i]) for i in range(TAIL)]
+    top2 = torch.topk(lg_ref, 2, dim=-1)
+    margins = (top2.values[:, 0] - top2.values[:, 1]).tolist()
+    sigma = (L - lg_ref).std(dim=-1).tolist()
+    decisive = 0
+    for i in range(TAIL):
+        if margins[i] > 6.0 * sigma[i]:
+            decisive += 1
+            assert picks[i] == int(top2.indices[i, 0]), (i, picks[i], int(top2.indices[i, 0]), margins[i], sigma[i])
+        if i + 1 < TAIL:
+            assert picks[i] == gen[T - S - TAIL + i + 1], i           # the graph-replayed free run emitted exactly the stepwise argmax
+    print(f"{shape}-shaped 2-layer model at cache positions {T - TAIL} .. {T - 1}: logits rel err worst {max(errs):.3e}, median {float(np.median(errs)):.3e}; "
+          f"{decisive}/{TAIL} decisive positions, all exact (oracle pass over {T} tokens: {time.time() - t0:.0f}s)")
+    assert max(errs) < 4e-3 and decisive >= 40
 
 
 def test_kv_bounds_and_errors(ctx):

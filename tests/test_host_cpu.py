@@ -322,6 +322,10 @@ def test_bench_launcher_dry_world2(launcher):
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"
     assert d["collective"]["backend"] == "gloo" and d["collective"]["world_seen"] == 2 and d["collective"]["gather_ms"] > 0
     assert d["clips_checked"] == 6
+    # the identity record of the process group (what proves, on an N-GPU node, that N ranks on N distinct devices took part): gathered over the group
+    c = d["collective"]
+    assert c["ranks_answered"] == 2 and c["world"] == 2 and [r["rank"] for r in c["ranks"]] == [0, 1] and len({r["pid"] for r in c["ranks"]}) == 2
+    assert all(set(r) >= {"host", "device_bdf", "numa_node"} for r in c["ranks"]) and c["rccl_version"] is None and c["distinct_devices"] == 0
 
 
 @pytest.mark.parametrize("n", [4, 8])
@@ -338,6 +342,48 @@ def test_bench_launcher_dry_world_4_8(n):
     assert d["n_gpus"] == n and d["config"]["parallelism"] == f"dp{n}" and d["scaling"] == "weak"
     assert d["collective"]["world_seen"] == n and d["clips_checked"] == 2 * n
     assert len(d["collective"].get("rank_ms_per_step", [0] * n)) == n
+
+
+def test_collective_identity_refuses_shared_devices_and_parses_the_rccl_log(tmp_path, monkeypatch):
+    """parallel.collective_identity: two ranks of one host on one GPU are refused unless the caller allows it (bench.py: PGV_BENCH_SHARE_DEVICE=1);
+    parallel.rccl_transport: the channel lines of an RCCL INFO log are counted into a P2P / SHM / NET verdict."""
+    from video_llava_amd import parallel
+    import torch.distributed as dist
+
+    class FakeDist:
+        @staticmethod
+        def is_initialized():
+            return True
+
+        @staticmethod
+        def get_backend():
+            return "gloo"
+
+        @staticmethod
+        def get_world_size():
+            return 2
+
+        @staticmethod
+        def all_gather_object(out, me):
+            out[0] = dict(me, rank=0, device_bdf="0000:05:00.0")
+            out[1] = dict(me, rank=1, device_bdf="0000:05:00.0", pid=me["pid"] + 1)
+    monkeypatch.setattr(parallel, "dist", FakeDist)
+    with pytest.raises(RuntimeError, match="share a GPU"):
+        parallel.collective_identity(torch.device("cpu"), 0, 2)
+    ok = parallel.collective_identity(torch.device("cpu"), 0, 2, allow_shared_device=True)
+    assert ok["ranks_answered"] == 2 and ok["distinct_devices"] == 1
+    with pytest.raises(RuntimeError, match="2 ranks answered, 3 expected"):
+        parallel.collective_identity(torch.device("cpu"), 0, 3, allow_shared_device=True)
+    monkeypatch.setattr(parallel, "dist", dist)
+    log = tmp_path / "rccl.log"
+    log.write_text("vm:1:1 [0] NCCL INFO Channel 00/0 : 0[0] -> 1[1] via P2P/IPC comm 0x1 nRanks 02\n"
+                   "vm:1:1 [0] NCCL INFO Channel 01/0 : 1[1] -> 0[0] via P2P/IPC comm 0x1 nRanks 02\n"
+                   "vm:1:1 [0] NCCL INFO === System : maxBw 48.0 totalBw 48.0 === XGMI\n")
+    monkeypatch.setattr(parallel, "_rccl_debug_file", str(log))
+    t = parallel.rccl_transport(cleanup=False)
+    assert t["p2p"] == 2 and t["shm"] == 0 and t["net"] == 0 and t["verdict"] == "P2P" and t["xgmi_mentions"] == 1 and t["log_lines"] == 3
+    log.write_text(log.read_text() + "vm:1:1 [0] NCCL INFO Channel 00 : 0[0] -> 1[1] via SHM/direct/direct\n")
+    assert parallel.rccl_transport(cleanup=False)["verdict"] == "SHM"
 
 
 def test_bench_gpus_mismatch_is_loud():

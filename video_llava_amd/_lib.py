@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpgv.so")
 
-ABI_VERSION = 300          # PGV_VERSION of include/pgv.h this table was written against
+ABI_VERSION = 310          # PGV_VERSION of include/pgv.h this table was written against
 PGV_OK, PGV_EINVAL, PGV_EHIP, PGV_ENOMEM, PGV_ESTATE, PGV_ENAME = 0, 1, 2, 3, 4, 5
 PGV_F16, PGV_BF16, PGV_F32 = 0, 1, 2
 EPI_NONE, EPI_BIAS, EPI_BIAS_QGELU, EPI_BIAS_GELU, EPI_RESID, EPI_BIAS_RESID, EPI_SWIGLU, EPI_F32 = range(8)
@@ -64,6 +64,8 @@ PROTOTYPES = {
     "pgv_kv_destroy": (None, [_vp]),
     "pgv_kv_len": (_i, [_vp, _i]),
     "pgv_llm_prefill": (_i, [_vp, _vp, _vp, _vp, C.POINTER(C.c_int32), _i, _vp, _i, C.POINTER(C.c_int32), _vp, _vp, _vp, _i, _vp]),
+    "pgv_llm_prefill_append": (_i, [_vp, _vp, _vp, _vp, C.POINTER(C.c_int32), _i, _vp, _i, C.POINTER(C.c_int32), _vp, _vp, _vp, _i, _vp]),
+    "pgv_kv_truncate": (_i, [_vp, _i, _i, _vp]),
     "pgv_llm_decode": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pgv_llm_decode_greedy": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "pgv_llm_sample": (_i, [_vp, _vp, _vp, _f, _i, _vp, _vp, _vp]),

@@ -5,6 +5,8 @@ Same conversation state machine (add_text -> answer), same prompt assembly (`<vi
 same stop-string handling and post-processing.  Device work runs in libpgv.  Two deliberate differences:
   * the reference re-runs the CLIP tower on the whole clip for EVERY turn (:137-144); here the pooled features of the uploaded clip
     are computed once in `upload_video` and reused by every `answer()` of the conversation (SURVEY.md 8f item 4);
+  * the reference re-runs the decoder over the WHOLE conversation every turn (:129-154); here a later turn prefills only the tokens behind the
+    prefix the KV cache already holds (`generate(kv_reuse_key=...)` -> pgv_llm_prefill_append) -- same tokens, `last_timings["reused_tokens"]`;
   * `PGVideoLLaVA` (grounding: GroundingDINO / SAM / DEVA / RAM / OpenAI entity matching, :225-333) and the WhisperX transcript model are
     side stacks outside the hot path: `--with_grounding` and `--use_asr` raise NotImplementedError.
 """
@@ -21,7 +23,7 @@ from .video_conversation import SeparatorStyle, conv_templates, default_conversa
 
 class VideoChatGPTInterface:
     def __init__(self, args_model_name, args_projection_path, use_asr=False, conv_mode="pg-video-llava", temperature=0.2,
-                 max_output_tokens=1024, components=None, do_sample=True) -> None:
+                 max_output_tokens=1024, components=None, do_sample=True, reuse_kv=True) -> None:
         if use_asr:
             raise NotImplementedError("--use_asr needs the WhisperX transcript stack, which is outside this package's hot path")
         self.use_asr = use_asr
@@ -34,6 +36,7 @@ class VideoChatGPTInterface:
         self.temperature = temperature
         self.max_new_tokens = max_output_tokens
         self.do_sample = do_sample
+        self.reuse_kv = reuse_kv
         self.frame_size = (image_processor.crop_size["height"], image_processor.crop_size["width"])
         if self.model.get_model().vision_config.use_vid_start_end:
             self.replace_token = DEFAULT_VID_START_TOKEN + DEFAULT_VIDEO_PATCH_TOKEN * video_token_len + DEFAULT_VID_END_TOKEN
@@ -44,6 +47,8 @@ class VideoChatGPTInterface:
     def clear_history(self):
         self.state = default_conversation.copy()
         self.video_features = None          # pooled [100 + P, 1024] features of the uploaded clip (computed once per clip)
+        self.kv_key = None                  # names the uploaded clip: later turns of the same clip continue the KV cache of the earlier ones
+        self.last_timings = {}
         self.video_path = None
         self.video_frames = None
         self.transcript_text = None
@@ -62,6 +67,7 @@ class VideoChatGPTInterface:
         self.video_path = video_path if isinstance(video_path, str) else None
         self.video_frames = frames
         self.video_features = video_features(frames, self.vision_tower, self.image_processor)
+        self.kv_key = object() if self.reuse_kv else None
         self.transcript_text = None
 
     def add_text(self, text, video_path):
@@ -103,7 +109,8 @@ class VideoChatGPTInterface:
         with torch.inference_mode():
             output_ids = self.model.generate(input_ids, video_spatio_temporal_features=self.video_features.unsqueeze(0),
                                              do_sample=self.do_sample, temperature=float(self.temperature),
-                                             max_new_tokens=min(int(self.max_new_tokens), 1536), stopping_criteria=[stopping_criteria])
+                                             max_new_tokens=min(int(self.max_new_tokens), 1536), stopping_criteria=[stopping_criteria],
+                                             kv_reuse_key=self.kv_key, timings=self.last_timings)
         n_in = input_ids.shape[1]
         n_diff = int((input_ids.to(output_ids.device) != output_ids[:, :n_in]).sum())
         if n_diff > 0:

@@ -351,12 +351,18 @@ static int lm_head_and_pick(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int B, int eos
 // ---------------------------------------------------------------------------------------------
 // prefill
 // ---------------------------------------------------------------------------------------------
-extern "C" int pgv_llm_prefill(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, const int32_t* h_ids, const int32_t* h_seq_lens, int B, const void* d_video,
-                               int Vt, const int32_t* h_vid_pos, float* d_logits, int32_t* d_next, float* d_all_logits, int ld_all, void* stream) {
-    PGV_CHECK(ctx && m && kv && h_ids && h_seq_lens, "pgv_llm_prefill: null argument");
-    PGV_CHECK(kv->llm == m, "pgv_llm_prefill: kv cache belongs to another model");
-    PGV_CHECK(B >= 1 && B <= kv->B, "pgv_llm_prefill: batch %d outside [1,%d]", B, kv->B);
-    if (pgv_llm_missing(m) != 0) { pgv_set_error("pgv_llm_prefill: %d weight tensors not loaded", pgv_llm_missing(m)); return PGV_ESTATE; }
+// `append`: the rows continue the sequences already in the cache (row p of sequence b sits at position h_len[b] + p and attends to the cached
+// prefix as well): VideoChatGPTLlamaForCausalLM.forward with past_key_values and input_ids.shape[1] > 1 (video_chatgpt/model/video_chatgpt.py:193-251;
+// the splice still runs when the new ids carry a placeholder run, :103).  Same kernels, same per-row arithmetic: an appended row is bitwise the
+// row of one full prefill over prefix + new tokens.
+static int prefill_impl(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, const int32_t* h_ids, const int32_t* h_seq_lens, int B, const void* d_video,
+                        int Vt, const int32_t* h_vid_pos, float* d_logits, int32_t* d_next, float* d_all_logits, int ld_all, void* stream, bool append) {
+    const char* who = append ? "pgv_llm_prefill_append" : "pgv_llm_prefill";
+    PGV_CHECK(ctx && m && kv && h_ids && h_seq_lens, "%s: null argument", who);
+    PGV_CHECK(kv->llm == m, "%s: kv cache belongs to another model", who);
+    PGV_CHECK(B >= 1 && B <= kv->B, "%s: batch %d outside [1,%d]", who, B, kv->B);
+    if (pgv_llm_missing(m) != 0) { pgv_set_error("%s: %d weight tensors not loaded", who, pgv_llm_missing(m)); return PGV_ESTATE; }
+    if (append && kv->active != B) { pgv_set_error("pgv_llm_prefill_append: %d sequences for a cache that holds %d prefilled ones", B, kv->active); return PGV_ESTATE; }
     hipStream_t s = (hipStream_t)stream;
     const int H = m->cfg.hidden, I = m->cfg.inter, heads = m->cfg.heads, vocab = m->cfg.vocab;
     // arrival tickets of the context-split decode attention: a launch re-arms its own, but an ABORTED decode launch (device fault, process kill
@@ -364,27 +370,29 @@ extern "C" int pgv_llm_prefill(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, const int32
     PGV_HIP(hipMemsetAsync(kv->dattn_ticket, 0, (size_t)kv->B * heads * sizeof(unsigned), s));
     int M = 0, max_len = 0;
     for (int b = 0; b < B; ++b) {
-        PGV_CHECK(h_seq_lens[b] >= 1 && h_seq_lens[b] <= kv->max_seq, "pgv_llm_prefill: sequence %d has %d tokens (cache holds %d)", b, h_seq_lens[b], kv->max_seq);
+        const int off = append ? kv->h_len[b] : 0;
+        PGV_CHECK(h_seq_lens[b] >= 1 && off + h_seq_lens[b] <= kv->max_seq, "%s: sequence %d has %d + %d tokens (cache holds %d)", who, b, off, h_seq_lens[b], kv->max_seq);
         M += h_seq_lens[b];
         if (h_seq_lens[b] > max_len) max_len = h_seq_lens[b];
     }
-    // ---- host-built row maps: [row_src | row_b | row_pos | cu (B+1) | last_rows (B) | lens (B)] ----
+    // ---- host-built row maps: [row_src | row_b | row_pos | cu (B+1) | last_rows (B) | lens (B) = positions after this call | offs (B)] ----
     std::vector<int>& meta = kv->h_meta;
-    meta.assign((size_t)3 * M + 3 * B + 1, 0);
-    int* row_src = meta.data(); int* row_b = row_src + M; int* row_pos = row_b + M; int* cu = row_pos + M; int* last = cu + B + 1; int* lens = last + B;
+    meta.assign((size_t)3 * M + 4 * B + 1, 0);
+    int* row_src = meta.data(); int* row_b = row_src + M; int* row_pos = row_b + M; int* cu = row_pos + M; int* last = cu + B + 1; int* lens = last + B; int* offs = lens + B;
     int r = 0;
     for (int b = 0; b < B; ++b) {
         cu[b] = r;
+        const int off = append ? kv->h_len[b] : 0;
         const int vp = (d_video && h_vid_pos) ? h_vid_pos[b] : -1;
-        if (vp >= 0) PGV_CHECK(vp + Vt + 1 < h_seq_lens[b], "pgv_llm_prefill: video run of sequence %d (start %d, %d rows) overruns its %d tokens", b, vp, Vt, h_seq_lens[b]);
+        if (vp >= 0) PGV_CHECK(vp + Vt + 1 < h_seq_lens[b], "%s: video run of sequence %d (start %d, %d rows) overruns its %d tokens", who, b, vp, Vt, h_seq_lens[b]);
         for (int p = 0; p < h_seq_lens[b]; ++p, ++r) {
             const int id = h_ids[r];
             const bool vid = vp >= 0 && p > vp && p <= vp + Vt;
-            if (!vid) PGV_CHECK(id >= 0 && id < vocab, "pgv_llm_prefill: token id %d at row %d outside the vocabulary (%d)", id, r, vocab);
+            if (!vid) PGV_CHECK(id >= 0 && id < vocab, "%s: token id %d at row %d outside the vocabulary (%d)", who, id, r, vocab);
             row_src[r] = vid ? -(b * Vt + (p - vp - 1) + 1) : id;
-            row_b[r] = b; row_pos[r] = p;
+            row_b[r] = b; row_pos[r] = off + p;
         }
-        last[b] = r - 1; lens[b] = h_seq_lens[b];
+        last[b] = r - 1; lens[b] = off + h_seq_lens[b]; offs[b] = off;
     }
     cu[B] = r;
 
@@ -400,13 +408,13 @@ extern "C" int pgv_llm_prefill(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, const int32
     PGV_CHECK(d_meta && resid && xn && qkv && ao && act, "pgv_llm_prefill: workspace exhausted");
     PGV_HIP(hipMemcpyAsync(d_meta, meta.data(), meta.size() * 4, hipMemcpyHostToDevice, s));
     const int* d_row_src = d_meta; const int* d_row_b = d_meta + M; const int* d_row_pos = d_row_b + M; const int* d_cu = d_row_pos + M;
-    const int* d_last = d_cu + B + 1; const int* d_lens = d_last + B;
+    const int* d_last = d_cu + B + 1; const int* d_lens = d_last + B; const int* d_offs = append ? d_lens + B : nullptr;
     PGV_HIP(hipMemcpyAsync(kv->d_pos, d_lens, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
     PGV_HIP(hipMemsetAsync(kv->d_step, 0, (size_t)2 * kv->B * 4, s));      // step + done
 
     PGV_TRY(pgv_launch_embed_splice(m->dtype, d_row_src, m->embed, d_video, resid, M, H, s));
     double attn_flops = 0;
-    for (int b = 0; b < B; ++b) attn_flops += 2.0 * (double)h_seq_lens[b] * h_seq_lens[b] * H;   // causal: 4*S^2*H/2
+    for (int b = 0; b < B; ++b) attn_flops += 2.0 * (double)h_seq_lens[b] * (h_seq_lens[b] + 2.0 * offs[b]) * H;   // causal: 4 * S * (S / 2 + prefix) * H
     for (int li = 0; li < m->cfg.layers; ++li) {
         const LlmLayer& l = m->layers[li];
         PGV_TRY(pgv_launch_rmsnorm(m->dtype, resid, l.in_g, m->cfg.eps, xn, M, H, s));
@@ -414,7 +422,7 @@ extern "C" int pgv_llm_prefill(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, const int32
         g.A = xn; g.lda = H; g.W = l.wqkv; g.ldw = H; g.bias = nullptr; g.C = qkv; g.ldc = 3 * H; g.M = M; g.N = 3 * H; g.K = H; g.epi = PGV_EPI_NONE; g.w_blocked = true;
         PGV_TRY(pgv_launch_gemm(ctx, m->dtype, g, s));
         PGV_TRY(pgv_launch_rope_kv_write(m->dtype, qkv, d_row_b, d_row_pos, m->rope, kv->Kc[li], kv->Vc[li], M, H, heads, kv->max_seq, s));
-        PGV_TRY(pgv_launch_prefill_attn(ctx, m->dtype, qkv, ao, kv->Kc[li], kv->Vc[li], d_cu, B, max_len, H, heads, kv->max_seq, attn_flops, s));
+        PGV_TRY(pgv_launch_prefill_attn(ctx, m->dtype, qkv, ao, kv->Kc[li], kv->Vc[li], d_cu, d_offs, B, max_len, H, heads, kv->max_seq, attn_flops, s));
         g = GemmArgs{}; g.A = ao; g.lda = H; g.W = l.wo; g.ldw = H; g.C = resid; g.ldc = H; g.M = M; g.N = H; g.K = H; g.epi = PGV_EPI_RESID; g.w_blocked = true;
         PGV_TRY(pgv_launch_gemm(ctx, m->dtype, g, s));
         PGV_TRY(pgv_launch_rmsnorm(m->dtype, resid, l.post_g, m->cfg.eps, xn, M, H, s));
@@ -426,7 +434,7 @@ extern "C" int pgv_llm_prefill(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, const int32
     if (d_all_logits) {
         // the reference's forward output: final norm + lm_head over ALL positions (video_chatgpt.py:225-226) -- on request only
         const int n16 = (vocab + 15) & ~15;
-        PGV_CHECK(ld_all >= n16 && ld_all % 4 == 0 && n16 <= m->vocab_cap, "pgv_llm_prefill: ld_all %d must be a multiple of 4 and at least %d", ld_all, n16);
+        PGV_CHECK(ld_all >= n16 && ld_all % 4 == 0 && n16 <= m->vocab_cap, "%s: ld_all %d must be a multiple of 4 and at least %d", who, ld_all, n16);
         PGV_TRY(pgv_launch_rmsnorm(m->dtype, resid, m->norm_g, m->cfg.eps, xn, M, H, s));
         GemmArgs g{};
         g.A = xn; g.lda = H; g.W = m->lm_head; g.ldw = H; g.C = d_all_logits; g.ldc = ld_all; g.M = M; g.N = n16; g.K = H; g.epi = PGV_EPI_F32; g.w_blocked = true;
@@ -443,10 +451,33 @@ extern "C" int pgv_llm_prefill(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, const int32
     }
     if (d_logits) PGV_HIP(hipMemcpyAsync(d_logits, kv->logits, (size_t)B * vocab * 4, hipMemcpyDeviceToDevice, s));
     if (d_next) PGV_HIP(hipMemcpyAsync(d_next, kv->d_cur, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
-    for (int b = 0; b < kv->B; ++b) kv->h_len[b] = b < B ? h_seq_lens[b] : 0;
+    for (int b = 0; b < kv->B; ++b) kv->h_len[b] = b < B ? lens[b] : 0;
     kv->active = B;
     PGV_HIP(hipGetLastError());
     PGV_TRY(pgv_ws_release(ctx, s));
+    return PGV_OK;
+}
+
+extern "C" int pgv_llm_prefill(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, const int32_t* h_ids, const int32_t* h_seq_lens, int B, const void* d_video,
+                               int Vt, const int32_t* h_vid_pos, float* d_logits, int32_t* d_next, float* d_all_logits, int ld_all, void* stream) {
+    return prefill_impl(ctx, m, kv, h_ids, h_seq_lens, B, d_video, Vt, h_vid_pos, d_logits, d_next, d_all_logits, ld_all, stream, false);
+}
+
+extern "C" int pgv_llm_prefill_append(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, const int32_t* h_ids, const int32_t* h_seq_lens, int B, const void* d_video,
+                                      int Vt, const int32_t* h_vid_pos, float* d_logits, int32_t* d_next, float* d_all_logits, int ld_all, void* stream) {
+    return prefill_impl(ctx, m, kv, h_ids, h_seq_lens, B, d_video, Vt, h_vid_pos, d_logits, d_next, d_all_logits, ld_all, stream, true);
+}
+
+// Drop the tail of sequence b: the next pgv_llm_prefill_append / decode call continues at position `len` (the entries beyond it are simply
+// overwritten).  What a chat turn needs when the new prompt shares only a prefix with the cached conversation (surplus decode steps past a stop
+// string, a re-tokenised answer).
+extern "C" int pgv_kv_truncate(pgv_kv* kv, int b, int len, void* stream) {
+    PGV_CHECK(kv != nullptr, "pgv_kv_truncate: null cache");
+    PGV_CHECK(b >= 0 && b < kv->active, "pgv_kv_truncate: sequence %d outside the %d prefilled ones", b, kv->active);
+    PGV_CHECK(len >= 1 && len <= kv->h_len[b], "pgv_kv_truncate: length %d outside [1,%d]", len, kv->h_len[b]);
+    kv->h_len[b] = len;
+    PGV_HIP(hipMemcpyAsync(kv->d_pos + b, &kv->h_len[b], 4, hipMemcpyHostToDevice, (hipStream_t)stream));
+    PGV_HIP(hipStreamSynchronize((hipStream_t)stream));          // the source is host bookkeeping that the next call may change
     return PGV_OK;
 }
 

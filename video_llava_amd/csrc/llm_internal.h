@@ -18,7 +18,7 @@ int pgv_launch_embed_splice(int dtype, const int* row_src, const void* embed, co
 int pgv_launch_gather_rows(const float* src, const int* rows, float* dst, int B, int H, hipStream_t s);
 int pgv_launch_rope_kv_write(int dtype, void* qkv, const int* row_b, const int* row_pos, const void* rope, void* Kc, void* Vc, int M, int H,
                              int heads, int max_seq, hipStream_t s);
-int pgv_launch_prefill_attn(pgv_ctx* ctx, int dtype, const void* qkv, void* out, const void* Kc, const void* Vc, const int* cu, int B, int max_len,
+int pgv_launch_prefill_attn(pgv_ctx* ctx, int dtype, const void* qkv, void* out, const void* Kc, const void* Vc, const int* cu, const int* koff, int B, int max_len,
                             int H, int heads, int max_seq, double flops, hipStream_t s);
 // gemv.hip
 int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void* x, int ldx, void* out, int ldo, int N, int K, int B, hipStream_t s,

@@ -1,7 +1,8 @@
 // LLaMA decoder, prompt side (HF:llama/modeling_llama.py; reference glue video_chatgpt/model/video_chatgpt.py):
 //   embed_splice   : embed_tokens gather + replacement of the <vid_patch> run by projected video rows (:100-168)
 //   rope_kv_write  : rotate-half RoPE on q,k (:129-160) + KV-cache append
-//   prefill_attn   : causal flash attention, head_dim 128, K/V streamed from the cache through LDS, MFMA
+//   prefill_attn   : causal flash attention, head_dim 128, K/V streamed from the cache through LDS, MFMA; with a per-sequence key offset the
+//                    new rows attend to the cached prefix as well (pgv_llm_prefill_append: forward() with past_key_values and S > 1)
 // (the prompt's projections run on the persistent GEMM of gemm.hip)
 #include "llm_internal.h"
 
@@ -77,6 +78,7 @@ struct PrefillAttnArgs {
     const char* Kc;       // [B, heads, max_seq, 128]
     const char* Vc;
     const int* cu;        // [B+1] row offsets
+    const int* koff;      // [B] tokens already in the cache in front of this call's rows (null: 0) -- query i sits at position koff + i
     int H, heads, max_seq;
     float scale_log2e;
 };
@@ -91,8 +93,11 @@ __global__ __launch_bounds__(256) void prefill_attn_kernel(PrefillAttnArgs p) {
     const int r0 = p.cu[b], S = p.cu[b + 1] - r0;
     const int q0 = blockIdx.x * 128;
     if (q0 >= S) return;
+    const int off = p.koff ? p.koff[b] : 0;           // cached prefix: keys [0, off) precede this call's rows; Tk = off + S keys exist
+    const int Tk = off + S;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int qi = q0 + w * 32 + l31;                 // this lane's query index within the sequence
+    const int qi = q0 + w * 32 + l31;                 // this lane's query index within this call's rows of the sequence
+    const int qpos = off + qi;                        // ... and its position
     const int qrow = r0 + min(qi, S - 1);
     const char* kbase = p.Kc + ((size_t)b * p.heads + h) * p.max_seq * HD * 2;
     const char* vbase = p.Vc + ((size_t)b * p.heads + h) * p.max_seq * HD * 2;
@@ -116,7 +121,10 @@ __global__ __launch_bounds__(256) void prefill_attn_kernel(PrefillAttnArgs p) {
     const int li = lane & 15, lg = (lane >> 4) & 1;
     const int voff0 = (4 * hi + (li >> 2)) * 256 + (((lg * 2 + ((li & 3) >> 1)) ^ ((li >> 2) << 2)) << 4) + (li & 1) * 8;   // d block j: ^ (j * 64)
 
-    const int kend = min(S, q0 + 128);
+    // Key chunks are aligned to ABSOLUTE positions (multiples of 64) whatever the offset and the query tile, a chunk a query cannot see adds
+    // exact zeros (alpha = 1, p = 0): a row's result does not depend on how the prompt was cut into calls -- an appended row is bitwise the row
+    // of one full prefill.
+    const int kend = min(Tk, off + q0 + 128);
     for (int kc0 = 0; kc0 < kend; kc0 += 64) {
         __syncthreads();
         // stage K: wave-instruction = 4 rows x 256 B
@@ -127,7 +135,7 @@ __global__ __launch_bounds__(256) void prefill_attn_kernel(PrefillAttnArgs p) {
                 const int g = w * 4 + g4;                  // 16 groups of 4 rows
                 const int row = g * 4 + srow;
                 const int chunk = slot ^ (row & 15);
-                const int kr = min(kc0 + row, S - 1);
+                const int kr = min(kc0 + row, Tk - 1);
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + ((size_t)kr * HD + chunk * 8) * 2),
                                                  (__attribute__((address_space(3))) void*)(Ks + g * 1024), 16, 0, 0);
             }
@@ -142,14 +150,14 @@ __global__ __launch_bounds__(256) void prefill_attn_kernel(PrefillAttnArgs p) {
                 const int g = w * 4 + g4;
                 const int row = g * 4 + srow;
                 const int chunk = slot ^ ((row & 3) << 2);
-                const int vr = min(kc0 + row, S - 1);      // rows past S: finite duplicates, their probabilities are exactly 0
+                const int vr = min(kc0 + row, Tk - 1);      // rows past Tk: finite duplicates, their probabilities are exactly 0
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + ((size_t)vr * HD + chunk * 8) * 2),
                                                  (__attribute__((address_space(3))) void*)(Vs + g * 1024), 16, 0, 0);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (kc0 > q0 + w * 32 + 31) continue;           // chunk entirely in this wave's future: nothing to add
+        if (kc0 > off + q0 + w * 32 + 31) continue;     // chunk entirely in this wave's future: nothing to add
 
         f32x16_t s[2];
 #pragma unroll
@@ -170,7 +178,7 @@ __global__ __launch_bounds__(256) void prefill_attn_kernel(PrefillAttnArgs p) {
             for (int e = 0; e < 16; ++e) {
                 const int key = kc0 + c * 32 + 4 * hi + (e & 3) + 8 * (e >> 2);
                 float v = s[c][e] * p.scale_log2e;
-                v = (key <= qi && key < S) ? v : NEG;
+                v = (key <= qpos && key < Tk) ? v : NEG;
                 s[c][e] = v;
                 cmax = fmaxf(cmax, v);
             }
@@ -245,10 +253,10 @@ int pgv_launch_rope_kv_write(int dtype, void* qkv, const int* row_b, const int* 
                                                     (const float2*)rope, (typename T::elem*)Kc, (typename T::elem*)Vc, H, heads, max_seq));
     return PGV_OK;
 }
-int pgv_launch_prefill_attn(pgv_ctx* ctx, int dtype, const void* qkv, void* out, const void* Kc, const void* Vc, const int* cu, int B, int max_len,
+int pgv_launch_prefill_attn(pgv_ctx* ctx, int dtype, const void* qkv, void* out, const void* Kc, const void* Vc, const int* cu, const int* koff, int B, int max_len,
                             int H, int heads, int max_seq, double flops, hipStream_t s) {
     PrefillAttnArgs a;
-    a.qkv = (const char*)qkv; a.out = (char*)out; a.Kc = (const char*)Kc; a.Vc = (const char*)Vc; a.cu = cu;
+    a.qkv = (const char*)qkv; a.out = (char*)out; a.Kc = (const char*)Kc; a.Vc = (const char*)Vc; a.cu = cu; a.koff = koff;
     a.H = H; a.heads = heads; a.max_seq = max_seq;
     a.scale_log2e = 0.08838834764831845f * 1.4426950408889634f;    // 128^-0.5 * log2(e)
     dim3 grid((max_len + 127) / 128, heads, B);

@@ -85,9 +85,10 @@ class PastKeyValues:
     """What forward() hands back as `past_key_values`: the library's KV-cache handle (the cache lives in HBM inside libpgv; HF's tuple of
     tensors / DynamicCache has no counterpart).  Truthy once it holds tokens, like the tuple the reference tests at model/video_chatgpt.py:256."""
 
-    def __init__(self, owner, kv, batch: int, seq_len: int):
+    def __init__(self, owner, kv, batch: int, seq_len: int, max_seq: int, epoch: int):
         self.owner, self.kv, self.batch, self.seq_len = owner, kv, batch, seq_len
-        self.max_seq = min(int(owner.config.max_position_embeddings), 4096)
+        self.max_seq = max_seq          # capacity of the cache behind `kv`
+        self.epoch = epoch              # the model's cache epoch when this object was handed out: any later prefill / generate makes it stale
 
     def get_seq_length(self, layer_idx: int = 0) -> int:
         return self.seq_len
@@ -129,6 +130,8 @@ class VideoChatGPTLlamaForCausalLM(nn.Module):
         _lib.check(self.ctx.lib.pgv_llm_create(self.ctx.handle, C.byref(lc), _lib.dtype_code(torch_dtype), C.byref(h)), "pgv_llm_create")
         self.handle = h
         self._kv: dict = {}
+        self._kv_epoch = 0              # bumped by every call that (re)fills a cache from position 0: what PastKeyValues objects are checked against
+        self._reuse = None              # generate(kv_reuse_key=...): (key, kv handle, max_seq, ids whose keys / values sit in the cache)
 
     def __del__(self):
         try:
@@ -199,6 +202,8 @@ class VideoChatGPTLlamaForCausalLM(nn.Module):
         for kv in self._kv.values():                    # logits buffers / captured decode graphs carry the old vocabulary size
             self.ctx.lib.pgv_kv_destroy(kv)
         self._kv.clear()
+        self._kv_epoch += 1
+        self._reuse = None
 
     # ---- weights ----------------------------------------------------------------------------------------
     def _expected_shape(self, key: str):
@@ -322,16 +327,34 @@ class VideoChatGPTLlamaForCausalLM(nn.Module):
             for old in self._kv.values():               # keep one cache alive (they are GBs)
                 self.ctx.lib.pgv_kv_destroy(old)
             self._kv.clear()
+            self._reuse = None
             h = C.c_void_p()
             _lib.check(self.ctx.lib.pgv_kv_create(self.ctx.handle, self.handle, batch, max_seq, C.byref(h)), "pgv_kv_create")
             self._kv[key] = h
         return self._kv[key]
 
+    def _reusable_prefix(self, key, ids: Sequence[int], max_new_tokens: int) -> int:
+        """Positions of the cache kept by the last generate(kv_reuse_key=key) that the prompt `ids` can start from (0: none -- full prefill)."""
+        r = self._reuse
+        if r is None or r[0] != key or self._kv.get((1, r[2])) is not r[1] or len(ids) + max_new_tokens > r[2]:
+            return 0
+        cached = r[3]
+        n = min(len(cached), len(ids) - 1)                 # at least one new token has to run: its logits pick the first answer token
+        a, b = np.asarray(cached[:n]), np.asarray(ids[:n])
+        diff = np.flatnonzero(a != b)
+        L = int(diff[0]) if diff.size else n
+        vc = self.model.vision_config
+        video_ids = [t for t in (vc.vid_patch_token, vc.vid_start_token, vc.vid_end_token) if t is not None]
+        if L < 1 or np.isin(np.asarray(ids[L:]), video_ids).any():
+            return 0                                       # the placeholder run is (partly) in the new tokens: it needs the splice of a full prefill
+        return L
+
     # ---- low-level steps (used by generate and by the parity tests) -------------------------------------
     def prefill(self, seqs: Sequence[Sequence[int]], video_spatio_temporal_features: Optional[torch.Tensor], max_seq: int,
-                want_logits: bool = False, want_all_logits: bool = False):
+                want_logits: bool = False, want_all_logits: bool = False, append_to=None):
         """Run the prompt(s); returns (kv handle, next-token ids [B] int32 on device, logits [B, vocab] or None) -- with want_all_logits a fourth
-        entry: the logits of EVERY position, [sum of lengths, vocab] fp32 (what the reference's forward returns, model/video_chatgpt.py:225-226)."""
+        entry: the logits of EVERY position, [sum of lengths, vocab] fp32 (what the reference's forward returns, model/video_chatgpt.py:225-226).
+        `append_to` = a kv handle this model filled before: the rows continue its sequences (pgv_llm_prefill_append; `max_seq` is ignored)."""
         B = len(seqs)
         lens = [len(s) for s in seqs]
         feats = video_spatio_temporal_features
@@ -349,7 +372,12 @@ class VideoChatGPTLlamaForCausalLM(nn.Module):
             if proj.shape[0] != B:
                 raise ValueError(f"{proj.shape[0]} video feature sets for {B} prompts")
             vid_pos = self._video_positions(seqs, V)
-        kv = self._get_kv(max(B, 1), max_seq)
+        if append_to is None:
+            kv = self._get_kv(max(B, 1), max_seq)
+            self._kv_epoch += 1
+            self._reuse = None
+        else:
+            kv = append_to
         flat = np.concatenate([np.asarray(s, dtype=np.int32) for s in seqs])
         h_lens = (C.c_int32 * B)(*lens)
         h_pos = (C.c_int32 * B)(*vid_pos)
@@ -357,11 +385,12 @@ class VideoChatGPTLlamaForCausalLM(nn.Module):
         logits = torch.empty(B, self.vocab_size, dtype=torch.float32, device=self.device_) if want_logits else None
         ld_all = (self.vocab_size + 15) // 16 * 16
         all_logits = torch.empty(int(flat.size), ld_all, dtype=torch.float32, device=self.device_) if want_all_logits else None
-        _lib.check(self.ctx.lib.pgv_llm_prefill(self.ctx.handle, self.handle, kv, flat.ctypes.data_as(C.c_void_p), h_lens, B,
-                                                proj.data_ptr() if proj is not None else None, V, h_pos,
-                                                logits.data_ptr() if logits is not None else None, nxt.data_ptr(),
-                                                all_logits.data_ptr() if all_logits is not None else None, ld_all,
-                                                _lib.stream_ptr(self.device_)), "pgv_llm_prefill")
+        fn, who = (self.ctx.lib.pgv_llm_prefill, "pgv_llm_prefill") if append_to is None else (self.ctx.lib.pgv_llm_prefill_append, "pgv_llm_prefill_append")
+        _lib.check(fn(self.ctx.handle, self.handle, kv, flat.ctypes.data_as(C.c_void_p), h_lens, B,
+                      proj.data_ptr() if proj is not None else None, V, h_pos,
+                      logits.data_ptr() if logits is not None else None, nxt.data_ptr(),
+                      all_logits.data_ptr() if all_logits is not None else None, ld_all,
+                      _lib.stream_ptr(self.device_)), who)
         if want_all_logits:
             return kv, nxt, logits, all_logits[:, :self.vocab_size]
         return kv, nxt, logits
@@ -404,10 +433,12 @@ class VideoChatGPTLlamaForCausalLM(nn.Module):
     @torch.no_grad()
     def forward(self, input_ids=None, attention_mask=None, past_key_values=None, inputs_embeds=None, labels=None, use_cache=None,
                 output_attentions=None, output_hidden_states=None, video_spatio_temporal_features: Optional[torch.Tensor] = None,
-                return_dict=None, **_unused):
+                return_dict=None, max_length: Optional[int] = None, **_unused):
         """`model(input_ids=ids, video_spatio_temporal_features=f, use_cache=True)` -> object with `.logits` [B, S, vocab] and `.past_key_values`;
         `model(input_ids=tok [B, 1], past_key_values=out.past_key_values, ...)` -> the next step (`input_ids.shape[1] == 1` skips the splice,
-        :103).  This is the recipe SURVEY.md 8c drives the reference with (prefill + cached single-token steps); `generate()` is the fast path
+        :103); `input_ids [B, S > 1]` next to a cache appends S tokens per sequence (a later chat turn) and returns their S logit rows.
+        `max_length` (first call): positions the cache is allocated for (default: prompt + 256).
+        This is the recipe SURVEY.md 8c drives the reference with (prefill + cached single-token steps); `generate()` is the fast path
         and what the reference's own callers use.  Inference only: `labels`, `inputs_embeds`, attention / hidden-state outputs and a padded
         `attention_mask` have no counterpart in the eval path and raise; logits are fp32 (HF up-casts them for the loss the same way)."""
         if labels is not None or inputs_embeds is not None or output_attentions or output_hidden_states:
@@ -421,20 +452,32 @@ class VideoChatGPTLlamaForCausalLM(nn.Module):
         B, S = ids.shape
         if attention_mask is not None and not bool(torch.as_tensor(attention_mask).to(torch.bool).all()):
             raise NotImplementedError("forward(): padded batches are not supported; pass equal-length prompts or use generate() with a list of prompts")
+        limit = min(int(self.config.max_position_embeddings), 4096)
         if past_key_values is None:
-            max_seq = min(int(self.config.max_position_embeddings), 4096)
+            # cache capacity: the prompt + `max_length` headroom (default 256 further positions, rounded up to 64) -- NOT the whole context window
+            # (2 GiB per 7B sequence at 4096 positions, and a second cache shape evicts the one generate() was using)
+            max_seq = min(limit, (int(max_length) if max_length is not None else S + 256) + 63 & ~63)
             if S > max_seq:
-                raise ValueError(f"prompt of {S} tokens exceeds max_position_embeddings {max_seq}")
+                raise ValueError(f"prompt of {S} tokens exceeds {'max_length' if max_length is not None and S <= limit else 'max_position_embeddings'} {max_seq}")
             kv, _nxt, _lg, all_lg = self.prefill([row.tolist() for row in ids.cpu()], video_spatio_temporal_features, max_seq, want_all_logits=True)
-            return CausalLMOutputWithPast(all_lg.reshape(B, S, -1), PastKeyValues(self, kv, B, S))
+            return CausalLMOutputWithPast(all_lg.reshape(B, S, -1), PastKeyValues(self, kv, B, S, max_seq, self._kv_epoch))
         if not isinstance(past_key_values, PastKeyValues) or past_key_values.owner is not self:
             raise ValueError("past_key_values must be the object a previous forward() of this model returned")
-        if S != 1:
-            raise NotImplementedError("forward() with a cache consumes one token per sequence (the reference's decode step, input_ids.shape[1] == 1)")
         if past_key_values.batch != B:
             raise ValueError(f"{B} sequences for a cache of {past_key_values.batch}")
-        if self._kv.get((past_key_values.batch, past_key_values.max_seq)) is not past_key_values.kv:
+        # one KV cache is kept alive per model and a later prefill of the SAME shape refills it in place: the epoch, not the handle, tells
+        # whether this object still describes what the cache holds
+        if past_key_values.epoch != self._kv_epoch or self._kv.get((past_key_values.batch, past_key_values.max_seq)) is not past_key_values.kv:
             raise RuntimeError("past_key_values is stale: the model has run another prefill / generate since (one KV cache is kept alive per model)")
+        if past_key_values.seq_len + S > past_key_values.max_seq:
+            raise ValueError(f"{past_key_values.seq_len} cached + {S} new tokens exceed the cache's {past_key_values.max_seq} positions "
+                             f"(pass max_length= to the first forward(); the model's limit is {limit})")
+        if S != 1:
+            # any number of new tokens next to a cache (model/video_chatgpt.py:193-251; a later chat turn): prefill them behind the cached ones
+            _kv, _nxt, _lg, all_lg = self.prefill([row.tolist() for row in ids.cpu()], video_spatio_temporal_features, 0, want_all_logits=True,
+                                                  append_to=past_key_values.kv)
+            past_key_values.seq_len += S
+            return CausalLMOutputWithPast(all_lg.reshape(B, S, -1), past_key_values)
         _nxt, lg = self.decode_step(past_key_values.kv, ids[:, 0].to(device=self.device_, dtype=torch.int32).contiguous(), want_logits=True)
         past_key_values.seq_len += 1
         return CausalLMOutputWithPast(lg[:, None, :], past_key_values)
@@ -444,7 +487,8 @@ class VideoChatGPTLlamaForCausalLM(nn.Module):
     def generate(self, input_ids, video_spatio_temporal_features: Optional[torch.Tensor] = None, do_sample: bool = False,
                  temperature: float = 1.0, max_new_tokens: int = 1024, stopping_criteria=None, eos_token_id="config",
                  chunk: int = 32, generator: Optional[torch.Generator] = None, top_k: int = 50,
-                 stop_strings: Optional[Sequence[Optional[str]]] = None, tokenizer=None, timings: Optional[dict] = None, **_unused):
+                 stop_strings: Optional[Sequence[Optional[str]]] = None, tokenizer=None, timings: Optional[dict] = None,
+                 kv_reuse_key=None, **_unused):
         """Returns LongTensor [B, S + n_new] on the device, prompt echoed (checked by inference.py:115-117).
 
         input_ids: LongTensor [B, S] (equal-length prompts, the reference's case) or a list of id lists (ragged batch).
@@ -461,7 +505,12 @@ class VideoChatGPTLlamaForCausalLM(nn.Module):
         KeywordsStoppingCriteria (model/utils.py:6-26, passed at inference.py:101-102 with batch size 1): after every chunk each live
         sequence's new ids are checked with `first_stop_length` (the exact per-token criterion, scanned incrementally); a sequence that
         fired is cut there and finished, and the loop ends when every sequence has finished -- at most one chunk past the last stop.
-        `timings` (a dict) receives prefill_s / decode_s / steps of this call (host clock; the chunk boundaries are D2H syncs anyway)."""
+        `timings` (a dict) receives prefill_s / decode_s / steps of this call (host clock; the chunk boundaries are D2H syncs anyway).
+        `kv_reuse_key` (B == 1; any hashable naming the conversation's video, None = off): keep the KV cache of this call for the next one with
+        the same key -- a later chat turn whose prompt extends what the cache holds prefills only the NEW tokens behind the common prefix
+        (pgv_kv_truncate + pgv_llm_prefill_append; the reference re-runs the whole conversation every turn, chat.py:108-160).  The video run
+        must lie inside the common prefix (it was spliced when the cache was filled); otherwise the call falls back to a full prefill.  Token-
+        and logits-identical to the full prefill (appended rows are bitwise the rows of one pass).  `timings["reused_tokens"]` reports the prefix."""
         if torch.is_tensor(input_ids):
             seqs = [row.tolist() for row in input_ids.cpu()]
         else:
@@ -473,6 +522,8 @@ class VideoChatGPTLlamaForCausalLM(nn.Module):
         if max_seq > self.config.max_position_embeddings:
             raise ValueError(f"prompt + max_new_tokens = {max_seq} exceeds max_position_embeddings {self.config.max_position_embeddings}")
         max_seq = (max_seq + 63) // 64 * 64
+        if kv_reuse_key is not None and B == 1:
+            max_seq = min(int(self.config.max_position_embeddings), 4096)      # one cache for the whole conversation: later turns grow into it
         criteria = list(stopping_criteria) if stopping_criteria else []
         if criteria and B != 1:
             raise ValueError("stopping_criteria are evaluated on one sequence (the reference passes them with batch size 1 only)")
@@ -491,7 +542,17 @@ class VideoChatGPTLlamaForCausalLM(nn.Module):
         import time as _time
         _t0 = _time.perf_counter()
 
-        kv, nxt, _ = self.prefill(seqs, video_spatio_temporal_features, max_seq)
+        reused = 0
+        if kv_reuse_key is not None and B == 1:
+            reused = self._reusable_prefix(kv_reuse_key, seqs[0], max_new_tokens)
+        if reused:
+            kv = self._reuse[1]
+            if reused < len(self._reuse[3]):
+                _lib.check(self.ctx.lib.pgv_kv_truncate(kv, 0, reused, _lib.stream_ptr(self.device_)), "pgv_kv_truncate")
+            _kv, nxt, _ = self.prefill([seqs[0][reused:]], None, 0, append_to=kv)
+        else:
+            kv, nxt, _ = self.prefill(seqs, video_spatio_temporal_features, max_seq)
+        raw: List[int] = []                                # B == 1: every token the device emitted, stop cuts ignored (= what the cache holds, shifted by one)
         u = None
         if do_sample and max_new_tokens >= 1:
             u = torch.rand(max_new_tokens, B, device=self.device_, dtype=torch.float32, generator=generator)
@@ -534,7 +595,9 @@ class VideoChatGPTLlamaForCausalLM(nn.Module):
         n_gen = 0
         _t1 = _t0
         if max_new_tokens >= 1:
-            stop = absorb(nxt.cpu())
+            first = nxt.cpu()
+            raw.append(int(first[0]))
+            stop = absorb(first)
             _t1 = _time.perf_counter()
             n_gen = 1
             while not stop and n_gen < max_new_tokens:
@@ -544,6 +607,7 @@ class VideoChatGPTLlamaForCausalLM(nn.Module):
                 else:
                     toks = self.decode_greedy(kv, nxt, n, eos_i)
                 host = toks.cpu()
+                raw.extend(host[0].tolist())
                 if criteria:
                     for i in range(n):
                         stop = absorb(host[:, i])
@@ -572,7 +636,11 @@ class VideoChatGPTLlamaForCausalLM(nn.Module):
                 nxt = toks[:, n - 1].contiguous()
         if timings is not None:
             _t2 = _time.perf_counter()
-            timings.update(prefill_s=_t1 - _t0, decode_s=_t2 - _t1, steps=n_gen, batch=B)
+            timings.update(prefill_s=_t1 - _t0, decode_s=_t2 - _t1, steps=n_gen, batch=B, reused_tokens=reused)
+        if kv_reuse_key is not None and B == 1:
+            # the cache holds the prompt and every emitted token that was fed back (all but the last one)
+            self._reuse = (kv_reuse_key, kv, max_seq, list(seqs[0]) + raw[:-1])
+            assert self.ctx.lib.pgv_kv_len(kv, 0) == len(self._reuse[3]), (self.ctx.lib.pgv_kv_len(kv, 0), len(self._reuse[3]))
         width = max(len(s) + len(n_) for s, n_ in zip(seqs, new))
         pad = eos_i if eos_i >= 0 else 0
         out = torch.full((B, width), pad, dtype=torch.long)

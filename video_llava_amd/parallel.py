@@ -48,10 +48,105 @@ def init_distributed(backend: str | None = None, timeout_s: float | None = None)
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
             torch.cuda.set_device(local)
+            _arm_rccl_debug_capture()
             dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local), timeout=timeout)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world, timeout=timeout)
     return rank, world, local
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Proof of transport: what a reader of the bench line / runner log needs to see that the N ranks really ran over RCCL on N distinct GPUs and
+# which path the ring took.  Nothing here changes the data path.
+# ---------------------------------------------------------------------------------------------------------------------------
+_rccl_debug_file = None
+
+
+def _arm_rccl_debug_capture():
+    """Before the process group exists: route this process's RCCL INFO log to a private temp file (NCCL_DEBUG / NCCL_DEBUG_FILE are read when the
+    communicator is created), unless the user already directs it somewhere or PGV_RCCL_DEBUG_CAPTURE=0.  The channel set-up lines it holds
+    ("Channel 00/0 : 0[0] -> 1[1] via P2P/IPC ...", "... via SHM ...", "... via NET/Socket ...") are what rccl_transport() counts."""
+    global _rccl_debug_file
+    if os.environ.get("PGV_RCCL_DEBUG_CAPTURE", "1") == "0" or "NCCL_DEBUG_FILE" in os.environ:
+        _rccl_debug_file = os.environ.get("NCCL_DEBUG_FILE")
+        return
+    import tempfile
+    fd, path = tempfile.mkstemp(prefix=f"pgv_rccl_{os.getpid()}_", suffix=".log")
+    os.close(fd)
+    os.environ["NCCL_DEBUG_FILE"] = path
+    os.environ.setdefault("NCCL_DEBUG", "INFO")
+    _rccl_debug_file = path
+
+
+def rccl_transport(cleanup: bool = True) -> dict:
+    """Counts of the channel transports in this process's captured RCCL log: {"p2p", "shm", "net", "xgmi_mentions", "log_lines", "verdict"}.
+    verdict: "P2P" (every channel peer-to-peer: xGMI / PCIe P2P inside a node), "SHM" / "NET" (a fallback through host memory / sockets was
+    used for at least one channel), "none" (no channel lines: one rank, or the log was not captured)."""
+    import re
+    out = {"p2p": 0, "shm": 0, "net": 0, "xgmi_mentions": 0, "log_lines": 0, "verdict": "none", "captured": bool(_rccl_debug_file)}
+    path = _rccl_debug_file
+    if not path:
+        return out
+    try:
+        for cand in (path, path.replace("%h", os.uname().nodename).replace("%p", str(os.getpid()))):
+            if os.path.exists(cand):
+                with open(cand, errors="replace") as f:
+                    for line in f:
+                        out["log_lines"] += 1
+                        if re.search(r"\bvia P2P", line):
+                            out["p2p"] += 1
+                        elif re.search(r"\bvia SHM", line):
+                            out["shm"] += 1
+                        elif re.search(r"\bvia NET", line):
+                            out["net"] += 1
+                        if "XGMI" in line.upper():
+                            out["xgmi_mentions"] += 1
+                if cleanup and cand.startswith(os.path.join(os.path.dirname(cand), "pgv_rccl_")):
+                    try:
+                        os.remove(cand)
+                    except OSError:
+                        pass
+                break
+    except OSError:
+        return out
+    out["verdict"] = "NET" if out["net"] else ("SHM" if out["shm"] else ("P2P" if out["p2p"] else "none"))
+    return out
+
+
+def collective_identity(device, rank: int, world: int, allow_shared_device: bool = False) -> dict:
+    """Who took part in the process group: backend, RCCL version, and per rank (gathered over the group itself) the host, the GPU's PCI address
+    and its NUMA node.  Raises RuntimeError when fewer ranks answer than `world`, or when two ranks of one host sit on the same GPU and
+    `allow_shared_device` is not set (a mis-launched job -- every rank on device 0 -- must not produce a scaling number)."""
+    backend = dist.get_backend() if dist.is_initialized() else None
+    dev_index = (device.index or 0) if isinstance(device, torch.device) else int(device)
+    on_gpu = torch.cuda.is_available() and not (isinstance(device, torch.device) and device.type != "cuda")
+    me = {"rank": rank, "host": os.uname().nodename, "device_bdf": None, "numa_node": None, "pid": os.getpid()}
+    if on_gpu:
+        try:
+            me["device_bdf"] = _gpu_bdf(dev_index)
+            me["numa_node"] = gpu_numa_node(dev_index)
+        except Exception:                                        # noqa: BLE001
+            pass
+    ranks = [me]
+    if dist.is_initialized():
+        ranks = [None] * dist.get_world_size()
+        dist.all_gather_object(ranks, me)
+    version = None
+    if backend == "nccl":
+        try:
+            version = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:                                        # noqa: BLE001
+            version = None
+    seen = sum(1 for r in ranks if r is not None)
+    out = {"backend": backend, "rccl_version": version, "world": world, "ranks_answered": seen, "ranks": ranks}
+    if seen != world:
+        raise RuntimeError(f"collective_identity: {seen} ranks answered, {world} expected: {ranks}")
+    where = [(r["host"], r["device_bdf"]) for r in ranks if r["device_bdf"] is not None]
+    out["distinct_devices"] = len(set(where))
+    if len(set(where)) != len(where) and not allow_shared_device:
+        raise RuntimeError(f"collective_identity: two ranks share a GPU ({where}); one rank per GPU is the contract "
+                           "(PGV_BENCH_SHARE_DEVICE=1 allows it for control-flow checks)")
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -244,9 +339,14 @@ def run_sharded(n_items: int, infer_batch: Callable[..., tuple], max_new_tokens:
         import json
         spilled = spill_file(spill_path, rank)
         lens_h, toks_h = lengths.cpu().tolist(), tokens.cpu()
-        with open(spilled, "w") as f:
-            json.dump({"rank": rank, "world": world, "indices": mine, "length_offset": length_offset, "lengths": lens_h[:len(mine)],
-                       "tokens": [toks_h[j, :max(lens_h[j] - length_offset, 0)].tolist() for j in range(len(mine))]}, f)
+        try:
+            with open(spilled, "w") as f:
+                json.dump({"rank": rank, "world": world, "indices": mine, "length_offset": length_offset, "lengths": lens_h[:len(mine)],
+                           "tokens": [toks_h[j, :max(lens_h[j] - length_offset, 0)].tolist() for j in range(len(mine))]}, f)
+        except OSError as e:                                     # disk full / read-only output dir: the safety net is gone, the collective still has
+            import sys                                           # to run -- a rank that skipped it would park its peers for the whole timeout
+            print(f"[rank {rank}] could not write the rank-local answer file {spilled}: {e}; continuing into the collation", file=sys.stderr, flush=True)
+            spilled = None
     try:
         answers = gather_answers(tokens, lengths, n_items, rank, world, length_offset)
     except CollationError as e:
