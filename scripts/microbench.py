@@ -113,8 +113,41 @@ def bench_decode(ctx, dtype=torch.bfloat16):
             del ws
 
 
+def bench_decode_wide(ctx, dtype=torch.bfloat16):
+    """The consumer GEMVs (qkv, gate/up, lm_head) at 8 .. 64 sequences, HBM-cold weights (rotating copies): us per launch and TB/s of weight bytes.
+    With the lab library (PGV_LIB=lab) PGV_GEMV_ABLATE = 1 (no x loads) / 2 (no MFMA) / 4 (no weight loads) attributes the time."""
+    lib = ctx.lib
+    print(f"== decode gemv, wide batches (PGV_GEMV_ABLATE={os.environ.get('PGV_GEMV_ABLATE', '0')}) ==")
+    shapes = ((0, 12288, 4096, "qkv"), (2, 22016, 4096, "gate/up"), (3, 32003, 4096, "lm_head"))
+    if os.environ.get("PGV_WIDE_13B"):
+        shapes = ((0, 15360, 5120, "qkv13"), (2, 27648, 5120, "gate/up13"))
+    for (mode, N, K, name) in shapes:
+        ncopy = max(2, int(600e6 // (N * K * 2)) + 1)
+        Np = (N + 15) // 16 * 16
+        ws = []
+        for _ in range(ncopy):
+            src = (torch.randn(N, K, device=DEV) * 0.02).to(dtype)
+            dst = torch.zeros(Np, K, device=DEV, dtype=dtype)
+            _lib.check(lib.pgv_pack_blocked(ctx.handle, _lib.dtype_code(dtype), src.data_ptr(), N, K, dst.data_ptr(), _lib.stream_ptr()))
+            ws.append(dst)
+        torch.cuda.synchronize()
+        for B in (8, 16, 32, 48, 64):
+            x = torch.randn(B, K, device=DEV).to(dtype)
+            out = torch.empty(B, N, device=DEV) if mode == 3 else torch.empty(B, N // 2 if mode == 2 else N, device=DEV, dtype=dtype)
+            state = {"i": 0}
+
+            def f():
+                w = ws[state["i"] % ncopy]; state["i"] += 1
+                _lib.check(lib.pgv_gemv(ctx.handle, _lib.dtype_code(dtype), mode, w.data_ptr(), x.data_ptr(), K, out.data_ptr(), out.shape[1], N, K, B, _lib.stream_ptr()))
+            med, mn = timeit(f, iters=40)
+            print(f"{name:9s} N={N:6d} K={K:5d} B={B:2d}: {med * 1e3:7.1f} / {mn * 1e3:7.1f} us  {N * K * 2 / med / 1e9:6.2f} TB/s", flush=True)
+        del ws
+
+
 if __name__ == "__main__":
     which = set(sys.argv[1:]) or {"gemm", "attn", "gemv"}
+    if os.environ.get("PGV_LIB") == "lab":
+        _lib.use_lab_build()
     if "ablate" in which or os.environ.get("PGV_ATTN_ABLATE"):
         _lib.use_lab_build()               # the ablation switches exist only in libpgv_lab.so (-DPGV_LAB)
     ctx = _lib.Context.get(0)
@@ -126,6 +159,8 @@ if __name__ == "__main__":
         bench_vit_attn(ctx)
     if "gemv" in which:
         bench_decode(ctx)
+    if "gemvwide" in which:
+        bench_decode_wide(ctx)
 
 
 def bench_gemm_pad(ctx, dtype=torch.bfloat16):

@@ -37,7 +37,15 @@ struct GemvArgs {
     // [CT][...][16], with these tile strides in elements
     int ssq_ts, amax_ts;
     unsigned lds_bytes;                                        // gemv_k8_kernel: bytes of LDS for the x slice of one pass
+#ifdef PGV_LAB
+    int abl;           // lab builds only (PGV_GEMV_ABLATE; results are garbage): 1 = no x loads in the K loop, 2 = no MFMA, 4 = no weight loads
+#endif
 };
+#ifdef PGV_LAB
+#define GV_ABL(p, bit) (((p).abl & (bit)) != 0)
+#else
+#define GV_ABL(p, bit) false
+#endif
 
 // W8 = true streams the fp8 (e4m3) blocked copy of the matrix: one 16-byte load per lane carries the A fragments of TWO consecutive
 // k-blocks, the codes are widened to the activation dtype in registers (exact) and the per-row scale multiplies the fp32 result, so the
@@ -169,11 +177,12 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int kb = min(2 * g + h, kb_end - 1);
-                    if (!W8 || h == 0) {
+                    if ((!W8 || h == 0) && !GV_ABL(p, 4)) {
 #pragma unroll
                         for (int t = 0; t < TILES; ++t)
                             wf[u][W8 ? 0 : h][t] = __builtin_nontemporal_load((const wreg_t*)(wp[t] + (size_t)(W8 ? min(g, j_end - 1) : kb) * 1024));
                     }
+                    if (GV_ABL(p, 1)) continue;
                     if constexpr (!X2) {
 #pragma unroll
                         for (int ct = 0; ct < CT; ++ct) xf[u][h][ct] = xload((size_t)kb, ct);
@@ -213,13 +222,18 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
                         typename T::v8 wv;
                         if constexpr (W8) wv = fp8x8_to_v8<T>(wf[u][0][t][2 * h], wf[u][0][t][2 * h + 1]);      // widened once, used by every column tile
                         else wv = wf[u][h][t];
+                        if (GV_ABL(p, 2)) {
+#pragma unroll
+                            for (int ct = 0; ct < CT; ++ct) acc[t][ct][0] += (float)wv[0] + (float)xv[h][ct][0];
+                            continue;
+                        }
 #pragma unroll
                         for (int ct = 0; ct < CT; ++ct) acc[t][ct] = T::mfma16(wv, xv[h][ct], acc[t][ct]);
                     }
             }
         };
-        wreg_t wa[PU][WH][TILES], wb[PU][WH][TILES];
-        typename T::v8 xa[PU][XH][CT], xb[PU][XH][CT];
+        wreg_t wa[PU][WH][TILES] = {}, wb[PU][WH][TILES] = {};
+        typename T::v8 xa[PU][XH][CT] = {}, xb[PU][XH][CT] = {};
         load(wa, xa, 0);
         int i = 0;
         for (; i + 2 < nb; i += 2) {
@@ -438,12 +452,28 @@ __global__ __launch_bounds__(NWB * 64) void gemv_k8_kernel(GemvArgs p, f32x4_t* 
         wreg_t wa[PU][WH], wb[PU][WH];
         wload(wa, pass0);                                        // the first weight batch is in flight while the x slice is staged
         __syncthreads();                                         // the previous pass has been read by every wave
-        for (int c = tid; c < ng * Brows * 8; c += NWB * 64) {   // 16-byte chunks: (group, row, chunk)
-            const int ch = c & 7, row = (c >> 3) % Brows, gi = (c >> 3) / Brows;
-            const int g = j + 8 * (pass0 + gi), kb = 2 * g + (ch >> 2);
-            u32x4_t v = {0u, 0u, 0u, 0u};
-            if (row < p.B && kb < kblocks) v = *(const u32x4_t*)(p.x + ((size_t)row * p.ldx + (size_t)g * 64 + ch * 8) * 2);
-            *(u32x4_t*)(xs + ((size_t)(gi * Brows + row) * 128 + ((ch ^ (row & 7)) << 4))) = v;
+        if ((kblocks & 1) == 0) {
+            // LDS-DMA (round 6): one wave-instruction lands 8 rows x 128 B = 1 KiB linearly in LDS, every lane fetching the 16-byte chunk that
+            // belongs at its position (the XOR swizzle is applied on the SOURCE side); all instructions of a pass are in flight together.  (The
+            // first version loaded 16 bytes per thread into a register and stored it, an L2 round trip per loop iteration: 12 dependent
+            // iterations per pass at four column tiles -- most of the kernel's time at 64 sequences.)  Rows >= B re-read the last sequence:
+            // their tile columns are never stored.
+            const int srow = lane >> 3, pos = lane & 7;
+            for (int q = w; q < ng * Brows / 8; q += NWB) {
+                const int fr = q * 8 + srow, gi = fr / Brows, row = fr - gi * Brows;
+                const int g = j + 8 * (pass0 + gi), ch = pos ^ (row & 7);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.x + ((size_t)min(row, p.B - 1) * p.ldx + (size_t)g * 64 + ch * 8) * 2),
+                                                 (__attribute__((address_space(3))) void*)(xs + (size_t)q * 1024), 16, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {                                                 // K % 64 == 32: the last group holds one 32-block, its other half must read as zeros
+            for (int c = tid; c < ng * Brows * 8; c += NWB * 64) {   // 16-byte chunks: (group, row, chunk)
+                const int ch = c & 7, row = (c >> 3) % Brows, gi = (c >> 3) / Brows;
+                const int g = j + 8 * (pass0 + gi), kb = 2 * g + (ch >> 2);
+                u32x4_t v = {0u, 0u, 0u, 0u};
+                if (row < p.B && kb < kblocks) v = *(const u32x4_t*)(p.x + ((size_t)row * p.ldx + (size_t)g * 64 + ch * 8) * 2);
+                *(u32x4_t*)(xs + ((size_t)(gi * Brows + row) * 128 + ((ch ^ (row & 7)) << 4))) = v;
+            }
         }
         __syncthreads();
         auto mma = [&](wreg_t (&wf)[PU][WH], int gi0) {
@@ -713,6 +743,9 @@ int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void
     a.W = (const char*)W; a.x = (const char*)x; a.out = (char*)out; a.N = N; a.K = K; a.B = B; a.ldx = ldx; a.ldo = ldo; a.wscale = wscale;
     a.ssq_in = nullptr; a.nparts_in = 0; a.inv_h = 0.f; a.eps = 0.f; a.gamma = nullptr; a.xg = nullptr; a.ssq_out = nullptr; a.amax_val = nullptr; a.amax_idx = nullptr;
     a.ssq_ts = 0; a.amax_ts = 0; a.lds_bytes = 0;
+#ifdef PGV_LAB
+    a.abl = lab_switch("PGV_GEMV_ABLATE", 0);
+#endif
     PGV_CHECK(B <= 16 || norm == nullptr || (norm->ssq_ts > 0 && (norm->amax_val == nullptr || norm->amax_ts > 0)), "gemv: batches beyond 16 need the tile strides of the side arrays");
     if (norm) {
         a.ssq_ts = norm->ssq_ts; a.amax_ts = norm->amax_ts;
