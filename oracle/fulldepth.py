@@ -63,7 +63,7 @@ def teacher_forced_reference(w: dict, cfg: synth.LlamaCfg, ids, feats, cont, cac
     of n sequential steps: a 32-layer fp32 forward over ~540 tokens costs about what the 441-token prefill costs."""
     PATCH, START, END = cfg.vocab - 3, cfg.vocab - 2, cfg.vocab - 1
     with torch.no_grad():
-        lg = ollm.LlamaOracle(w, cfg, cache_weights=cache_weights).prefill(list(ids) + list(cont), feats, START, END, PATCH, all_logits=len(cont) + 1)
+        lg = ollm.LlamaOracle(w, cfg, cache_weights=cache_weights).prefill(list(ids) + list(cont), feats, START, END, PATCH, all_logits=len(cont) + 1, n_prompt=len(ids))
     top2 = torch.topk(lg, 2, dim=-1)
     return lg, (top2.values[:, 0] - top2.values[:, 1]).tolist(), top2.indices[:, 0].tolist()
 

@@ -154,14 +154,18 @@ class LlamaOracle:
         return x @ _t(w, "lm_head.weight", dt).t()
 
     def prefill(self, input_ids, video_feats: torch.Tensor | None, vid_start: int, vid_end: int,
-                vid_patch: int, all_logits: bool = False) -> torch.Tensor:
+                vid_patch: int, all_logits: bool = False, n_prompt: int | None = None) -> torch.Tensor:
         """input_ids [S] ints; video_feats [V, 1024] pooled CLIP features or None.
-        Returns logits [1, vocab] for the last position (all_logits=True: [S, vocab]; all_logits=n: the last n positions)."""
+        Returns logits [1, vocab] for the last position (all_logits=True: [S, vocab]; all_logits=n: the last n positions).
+        n_prompt: only the first n_prompt ids are the PROMPT (checked and spliced); the rest are tokens that followed it one at a time -- the
+        reference's forward with input_ids.shape[1] == 1 skips the splice and the placeholder checks (model/video_chatgpt.py:103), so a generated
+        <vid_start> is an ordinary embedding row there -- evaluated here in the same causal pass."""
         ids = torch.as_tensor(input_ids, dtype=torch.long)
         x = _t(self.w, "model.embed_tokens.weight", self.dtype)[ids]
-        if video_feats is not None and ids.shape[0] != 1:
+        n = ids.shape[0] if n_prompt is None else int(n_prompt)
+        if video_feats is not None and n != 1:
             proj = mm_projector(video_feats.to(self.dtype), self.w, self.cfg.projector)
-            x = splice_video_embeddings(ids, x, proj, vid_start, vid_end, vid_patch)
+            x = torch.cat([splice_video_embeddings(ids[:n], x[:n], proj, vid_start, vid_end, vid_patch), x[n:]], dim=0)
         return self._forward_embeds(x, all_logits)
 
     def step(self, token: int) -> torch.Tensor:

@@ -117,7 +117,7 @@ def bench_decode_wide(ctx, dtype=torch.bfloat16):
     """The consumer GEMVs (qkv, gate/up, lm_head) at 8 .. 64 sequences, HBM-cold weights (rotating copies): us per launch and TB/s of weight bytes.
     With the lab library (PGV_LIB=lab) PGV_GEMV_ABLATE = 1 (no x loads) / 2 (no MFMA) / 4 (no weight loads) attributes the time."""
     lib = ctx.lib
-    print(f"== decode gemv, wide batches (PGV_GEMV_ABLATE={os.environ.get('PGV_GEMV_ABLATE', '0')}) ==")
+    print(f"== decode gemv, wide batches (PGV_GEMV_ABLATE={os.environ.get('PGV_GEMV_ABLATE', '0')} PGV_XPAD={os.environ.get('PGV_XPAD', '0')} PGV_GEMV_XBLK={os.environ.get('PGV_GEMV_XBLK', '0')}) ==")
     shapes = ((0, 12288, 4096, "qkv"), (2, 22016, 4096, "gate/up"), (3, 32003, 4096, "lm_head"))
     if os.environ.get("PGV_WIDE_13B"):
         shapes = ((0, 15360, 5120, "qkv13"), (2, 27648, 5120, "gate/up13"))
@@ -131,14 +131,24 @@ def bench_decode_wide(ctx, dtype=torch.bfloat16):
             _lib.check(lib.pgv_pack_blocked(ctx.handle, _lib.dtype_code(dtype), src.data_ptr(), N, K, dst.data_ptr(), _lib.stream_ptr()))
             ws.append(dst)
         torch.cuda.synchronize()
+        xpad = int(os.environ.get("PGV_XPAD", "0"))
+        xblk = os.environ.get("PGV_GEMV_XBLK", "0") != "0"
         for B in (8, 16, 32, 48, 64):
-            x = torch.randn(B, K, device=DEV).to(dtype)
+            xbuf = torch.randn(B, K + xpad, device=DEV).to(dtype)
+            x = xbuf[:, :K]
+            ldx = K + xpad
+            if xblk and B > 16:                              # [K/32][CT][4 k-groups][16 sequences][8]: one contiguous 1 KiB wave-load per B fragment
+                CT = 2 if B <= 32 else 4
+                xp = torch.zeros(CT * 16, K, device=DEV, dtype=dtype)
+                xp[:B] = x
+                x = xp.view(CT, 16, K // 32, 4, 8).permute(2, 0, 3, 1, 4).contiguous()
+                ldx = K
             out = torch.empty(B, N, device=DEV) if mode == 3 else torch.empty(B, N // 2 if mode == 2 else N, device=DEV, dtype=dtype)
             state = {"i": 0}
 
             def f():
                 w = ws[state["i"] % ncopy]; state["i"] += 1
-                _lib.check(lib.pgv_gemv(ctx.handle, _lib.dtype_code(dtype), mode, w.data_ptr(), x.data_ptr(), K, out.data_ptr(), out.shape[1], N, K, B, _lib.stream_ptr()))
+                _lib.check(lib.pgv_gemv(ctx.handle, _lib.dtype_code(dtype), mode, w.data_ptr(), x.data_ptr(), ldx, out.data_ptr(), out.shape[1], N, K, B, _lib.stream_ptr()))
             med, mn = timeit(f, iters=40)
             print(f"{name:9s} N={N:6d} K={K:5d} B={B:2d}: {med * 1e3:7.1f} / {mn * 1e3:7.1f} us  {N * K * 2 / med / 1e9:6.2f} TB/s", flush=True)
         del ws

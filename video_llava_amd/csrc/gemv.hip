@@ -37,6 +37,12 @@ struct GemvArgs {
     // [CT][...][16], with these tile strides in elements
     int ssq_ts, amax_ts;
     unsigned lds_bytes;                                        // gemv_k8_kernel: bytes of LDS for the x slice of one pass
+    // Batches beyond 16 (round 6): the activation operand of the CONSUMERS (qkv, gate/up, lm_head) is in the fragment-blocked activation layout
+    // [K / 32][CT][4 k-groups][16 sequences][8 elements] (gv_xblk_offset): an MFMA B fragment is one contiguous 1 KiB wave-load, like a weight
+    // fragment, instead of 16 rows x 64 B.  The activation operand is re-read by every workgroup and at 64 sequences it is MORE bytes on a CU's
+    // load path than its weights (512 KB against 393 KB for qkv); with row-major rows the loads alone took 26 us of the 38 us qkv launch
+    // (x-only ablation, LAB.md), blocked 19.  xblk: x is blocked; xgblk: the producer writes xg blocked.
+    int xblk, xgblk;
 #ifdef PGV_LAB
     int abl;           // lab builds only (PGV_GEMV_ABLATE; results are garbage): 1 = no x loads in the K loop, 2 = no MFMA, 4 = no weight loads
 #endif
@@ -142,12 +148,16 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
     // >= B point outside the buffer descriptor, so they cost no request on the load path (with B = 8 half of every 1 KiB wave-load; the
     // activations are re-read by every workgroup and the per-CU load path, not HBM, is what the fp8 GEMVs run into).  Their zeros only
     // feed output columns that are never stored.
-    const __amdgpu_buffer_rsrc_t xrs = gv_make_rsrc(p.x, (unsigned)(((size_t)(p.B - 1) * p.ldx + p.K) * 2));
+    const bool xblk = p.xblk != 0;
+    const __amdgpu_buffer_rsrc_t xrs = gv_make_rsrc(p.x, xblk ? (unsigned)((size_t)kblocks * CT * 1024) : (unsigned)(((size_t)(p.B - 1) * p.ldx + p.K) * 2));
     unsigned xvo[CT];
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) xvo[ct] = ct * 16 + l15 < p.B ? (unsigned)(((size_t)(ct * 16 + l15) * p.ldx + kg * 8) * 2) : 0x80000000u;
+    for (int ct = 0; ct < CT; ++ct)
+        xvo[ct] = xblk ? (ct * 16 < p.B ? (unsigned)((ct * 64 + lane) * 16) : 0x80000000u)          // whole tiles beyond B: outside the descriptor, no request
+                       : (ct * 16 + l15 < p.B ? (unsigned)(((size_t)(ct * 16 + l15) * p.ldx + kg * 8) * 2) : 0x80000000u);
+    const unsigned xkb = xblk ? CT * 1024u : 64u;              // bytes between consecutive k-blocks of one column tile
     auto xload = [&](size_t kb, int ct) -> typename T::v8 {
-        return __builtin_bit_cast(typename T::v8, __builtin_amdgcn_raw_buffer_load_b128(xrs, xvo[ct] + (unsigned)(kb * 64), 0, 0));
+        return __builtin_bit_cast(typename T::v8, __builtin_amdgcn_raw_buffer_load_b128(xrs, xvo[ct] + (unsigned)kb * xkb, 0, 0));
     };
     f32x4_t acc[TILES][CT];
 #pragma unroll
@@ -321,7 +331,7 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
             const f32x4_t r = r_old[ct] + tot[0];
             *rp = r;
             const f32x4_t g = g_nx;
-            *(u32x2_t*)(p.xg + ((size_t)b * p.ldo + n0) * 2) = pack4<T>(r[0] * g[0], r[1] * g[1], r[2] * g[2], r[3] * g[3]);
+            *(u32x2_t*)(p.xg + (p.xgblk ? gv_xblk_offset(b, n0, CT) : ((size_t)b * p.ldo + n0) * 2)) = pack4<T>(r[0] * g[0], r[1] * g[1], r[2] * g[2], r[3] * g[3]);
             sq = (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
         }
         {   // sum over the four rows of 16 lanes (the 16 output rows of this workgroup) without LDS round trips
@@ -403,7 +413,7 @@ __device__ __forceinline__ void k8_finish_row_block(const GemvArgs& p, const f32
             const f32x4_t r = r_old[ct] + tot;
             *rp = r;
             const f32x4_t g = g_nx;
-            *(u32x2_t*)(p.xg + ((size_t)b * p.ldo + n0) * 2) = pack4<T>(r[0] * g[0], r[1] * g[1], r[2] * g[2], r[3] * g[3]);
+            *(u32x2_t*)(p.xg + (p.xgblk ? gv_xblk_offset(b, n0, CT) : ((size_t)b * p.ldo + n0) * 2)) = pack4<T>(r[0] * g[0], r[1] * g[1], r[2] * g[2], r[3] * g[3]);
             sq = (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
         }
         sq = rows_sum_to_row3(sq);
@@ -536,9 +546,10 @@ __global__ __launch_bounds__(64) void gemv_k8_finish_kernel(GemvArgs p, const f3
 
 // decode: resid[b] = embed[tok[b]] plus the producer side of the folded RMSNorm (see GemvArgs): xg = round16(resid * gamma of layer 0's
 // input norm), ssq[0][b] = sum resid^2 (one partial per sequence).
+// xct > 0: xg is written in the fragment-blocked activation layout with xct column tiles (gv_xblk_offset); 0: row-major [B][H].
 template <typename T>
 __global__ __launch_bounds__(256) void embed_tok_norm_kernel(const int* __restrict__ tok, const typename T::elem* __restrict__ embed, float* __restrict__ resid,
-                                                             const float* __restrict__ gamma, typename T::elem* __restrict__ xg, float* __restrict__ ssq, int H, int ssq_ts) {
+                                                             const float* __restrict__ gamma, typename T::elem* __restrict__ xg, float* __restrict__ ssq, int H, int ssq_ts, int xct) {
     __shared__ float red[4];
     const int b = blockIdx.x;
     const typename T::elem* p = embed + (size_t)tok[b] * H;
@@ -551,8 +562,9 @@ __global__ __launch_bounds__(256) void embed_tok_norm_kernel(const int* __restri
         *(f32x4_t*)(resid + (size_t)b * H + c) = a;
         *(f32x4_t*)(resid + (size_t)b * H + c + 4) = bb;
         const f32x4_t g0 = *(const f32x4_t*)(gamma + c), g1 = *(const f32x4_t*)(gamma + c + 4);
-        *(u32x2_t*)((char*)xg + ((size_t)b * H + c) * 2) = pack4<T>(a[0] * g0[0], a[1] * g0[1], a[2] * g0[2], a[3] * g0[3]);
-        *(u32x2_t*)((char*)xg + ((size_t)b * H + c + 4) * 2) = pack4<T>(bb[0] * g1[0], bb[1] * g1[1], bb[2] * g1[2], bb[3] * g1[3]);
+        char* xo = (char*)xg + (xct ? gv_xblk_offset(b, c, xct) : ((size_t)b * H + c) * 2);       // 8 consecutive features: 16 contiguous bytes in either layout
+        *(u32x2_t*)xo = pack4<T>(a[0] * g0[0], a[1] * g0[1], a[2] * g0[2], a[3] * g0[3]);
+        *(u32x2_t*)(xo + 8) = pack4<T>(bb[0] * g1[0], bb[1] * g1[1], bb[2] * g1[2], bb[3] * g1[3]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) ss += a[e] * a[e] + bb[e] * bb[e];
     }
@@ -566,13 +578,13 @@ __global__ __launch_bounds__(256) void embed_tok_norm_kernel(const int* __restri
 // before lm_head): xg = round16(resid * gamma), ssq[b] = sum resid^2.  One workgroup per row.
 template <typename T>
 __global__ __launch_bounds__(256) void resid_norm_prep_kernel(const float* __restrict__ resid, const float* __restrict__ gamma, typename T::elem* __restrict__ xg,
-                                                              float* __restrict__ ssq, int H, int ssq_ts) {
+                                                              float* __restrict__ ssq, int H, int ssq_ts, int xct) {
     __shared__ float red[4];
     const int b = blockIdx.x;
     float ss = 0.f;
     for (int c = threadIdx.x * 4; c < H; c += 256 * 4) {
         const f32x4_t r = *(const f32x4_t*)(resid + (size_t)b * H + c), g = *(const f32x4_t*)(gamma + c);
-        *(u32x2_t*)((char*)xg + ((size_t)b * H + c) * 2) = pack4<T>(r[0] * g[0], r[1] * g[1], r[2] * g[2], r[3] * g[3]);
+        *(u32x2_t*)((char*)xg + (xct ? gv_xblk_offset(b, c, xct) : ((size_t)b * H + c) * 2)) = pack4<T>(r[0] * g[0], r[1] * g[1], r[2] * g[2], r[3] * g[3]);
         ss += (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
     }
     ss = wave_sum(ss);
@@ -583,16 +595,22 @@ __global__ __launch_bounds__(256) void resid_norm_prep_kernel(const float* __res
 
 }  // namespace
 
-int pgv_launch_final_prep(int dtype, const float* resid, const float* gamma, void* xg, float* ssq, int B, int H, hipStream_t s) {
-    PGV_CHECK(H % 4 == 0, "final_prep: hidden %d unsupported", H);
-    PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((resid_norm_prep_kernel<T>), dim3(B), dim3(256), 0, s, resid, gamma, (typename T::elem*)xg, ssq, H, H));
+// Column tiles of the blocked activation layout for a batch of B sequences (0: row-major -- one MFMA tile of sequences needs no blocking: the
+// merged / masked row loads of the narrow kernels are cheaper there).  The ONE place that decides it: producers and consumers must agree.
+int pgv_gemv_xblk_tiles(int B) { return B <= 16 ? 0 : (B <= 32 ? 2 : 4); }
+
+int pgv_launch_final_prep(int dtype, const float* resid, const float* gamma, void* xg, float* ssq, int B, int H, hipStream_t s, bool x_blocked) {
+    PGV_CHECK(H % 32 == 0, "final_prep: hidden %d unsupported", H);
+    const int xct = x_blocked ? pgv_gemv_xblk_tiles(B) : 0;
+    PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((resid_norm_prep_kernel<T>), dim3(B), dim3(256), 0, s, resid, gamma, (typename T::elem*)xg, ssq, H, H, xct));
     return PGV_OK;
 }
 
-int pgv_launch_embed_tok_norm(int dtype, const int* tok, const void* embed, float* resid, const float* gamma, void* xg, float* ssq, int B, int H, hipStream_t s) {
-    PGV_CHECK(H % 8 == 0, "embed: hidden must be a multiple of 8");
+int pgv_launch_embed_tok_norm(int dtype, const int* tok, const void* embed, float* resid, const float* gamma, void* xg, float* ssq, int B, int H, hipStream_t s, bool x_blocked) {
+    PGV_CHECK(H % 32 == 0, "embed: hidden must be a multiple of 32");
+    const int xct = x_blocked ? pgv_gemv_xblk_tiles(B) : 0;
     PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((embed_tok_norm_kernel<T>), dim3(B), dim3(256), 0, s, tok, (const typename T::elem*)embed, resid, gamma,
-                                                    (typename T::elem*)xg, ssq, H, H));
+                                                    (typename T::elem*)xg, ssq, H, H, xct));
     return PGV_OK;
 }
 
@@ -742,15 +760,20 @@ int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void
     GemvArgs a;
     a.W = (const char*)W; a.x = (const char*)x; a.out = (char*)out; a.N = N; a.K = K; a.B = B; a.ldx = ldx; a.ldo = ldo; a.wscale = wscale;
     a.ssq_in = nullptr; a.nparts_in = 0; a.inv_h = 0.f; a.eps = 0.f; a.gamma = nullptr; a.xg = nullptr; a.ssq_out = nullptr; a.amax_val = nullptr; a.amax_idx = nullptr;
-    a.ssq_ts = 0; a.amax_ts = 0; a.lds_bytes = 0;
+    a.ssq_ts = 0; a.amax_ts = 0; a.lds_bytes = 0; a.xblk = 0; a.xgblk = 0;
 #ifdef PGV_LAB
     a.abl = lab_switch("PGV_GEMV_ABLATE", 0);
+    if (B > 16 && lab_switch("PGV_GEMV_XBLK", 0) != 0) a.xblk = 1;      // lab: the caller hands over x in the blocked layout (scripts/microbench.py gemvwide)
 #endif
     PGV_CHECK(B <= 16 || norm == nullptr || (norm->ssq_ts > 0 && (norm->amax_val == nullptr || norm->amax_ts > 0)), "gemv: batches beyond 16 need the tile strides of the side arrays");
     if (norm) {
         a.ssq_ts = norm->ssq_ts; a.amax_ts = norm->amax_ts;
         a.ssq_in = norm->ssq_in; a.nparts_in = norm->nparts_in; a.inv_h = 1.0f / (float)norm->hidden; a.eps = norm->eps;
         a.gamma = norm->gamma; a.xg = (char*)norm->xg; a.ssq_out = norm->ssq_out; a.amax_val = norm->amax_val; a.amax_idx = norm->amax_idx;
+        if (norm->x_blocked && pgv_gemv_xblk_tiles(B) > 0) {          // consumers read x blocked, producers write xg blocked
+            PGV_CHECK(K % 32 == 0 && N % 32 == 0, "gemv: the blocked activation layout needs K and N in multiples of 32");
+            if (mode == GV_RESIDNORM) a.xgblk = 1; else a.xblk = 1;
+        }
         PGV_CHECK(norm->nparts_in * 4 <= 3 * 8 * 64, "gemv: %d sum-of-squares partials exceed what a consumer workgroup loads (hidden <= 6144)", norm->nparts_in);
     }
     PGV_CHECK(mode != GV_RESIDNORM || (a.gamma && a.xg && a.ssq_out), "gemv: the residual+norm producer needs gamma / xg / ssq_out");

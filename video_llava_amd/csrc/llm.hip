@@ -276,7 +276,8 @@ extern "C" int pgv_kv_create(pgv_ctx* ctx, pgv_llm* llm, int batch, int max_seq,
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += pgv_align(bytes); return o; };
     const size_t o_cache = take(per * 2 * L);
-    const size_t o_resid = take(B * H * 4), o_xn = take(B * H * 2), o_qkv = take(B * 3 * H * 2), o_ao = take(B * H * 2), o_act = take(B * I * 2),
+    const size_t o_resid = take(B * H * 4), o_xn = take(CTn * 16 * H * 2),      // xn: row-major [B][H] up to 16 sequences, fragment-blocked [H / 32][CTn][4][16][8] beyond (gv_xblk_offset)
+                 o_qkv = take(B * 3 * H * 2), o_ao = take(B * H * 2), o_act = take(B * I * 2),
                  o_logits = take(B * V * 4), o_ssq = take(CTn * H * 4), o_av = take(CTn * V * 4), o_ai = take(CTn * V * 4), o_ints = take((4 * B + B * (size_t)max_seq) * 4),
                  o_u = take(B * (size_t)max_seq * 4), o_dpart = take(B * llm->cfg.heads * (size_t)kDattnSplitMax * kDattnPart * 4), o_dtick = take(B * llm->cfg.heads * 4),
                  o_k8 = take((H / 16) * 8 * CTn * 64 * 16);
@@ -293,6 +294,7 @@ extern "C" int pgv_kv_create(pgv_ctx* ctx, pgv_llm* llm, int batch, int max_seq,
     e = hipMemset(ints, 0, (4 * B + B * (size_t)max_seq) * 4);
     if (e == hipSuccess) e = hipMemset(kv->dattn_ticket, 0, B * llm->cfg.heads * 4);
     if (e == hipSuccess) e = hipMemset(kv->ssq, 0, CTn * H * 4);
+    if (e == hipSuccess) e = hipMemset(kv->xn, 0, CTn * 16 * H * 2);            // the columns of absent sequences are read (never stored): finite
     kv->ssq_ts = (int)H; kv->amax_ts = (int)V;
     if (e != hipSuccess) { (void)hipFree(kv->blob); delete kv; pgv_set_error("pgv_kv_create: memset: %s", hipGetErrorString(e)); return PGV_EHIP; }
     kv->h_len.assign(batch, 0);
@@ -333,6 +335,7 @@ static int lm_head_and_pick(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int B, int eos
     const int H = m->cfg.hidden, V = m->cfg.vocab;
     GemvNorm nm; nm.ssq_in = nparts > 0 ? kv->ssq : nullptr; nm.nparts_in = nparts; nm.hidden = H; nm.eps = m->cfg.eps;     // nparts 0: kv->xn is already normalised
     nm.ssq_ts = kv->ssq_ts; nm.amax_ts = kv->amax_ts;
+    nm.x_blocked = nparts > 0;                       // the folded path hands kv->xn over blocked at batches beyond 16 (pgv_gemv_xblk_tiles)
     const bool greedy = !(flags & AM_SAMPLE);
     if (greedy) { nm.amax_val = kv->amax_val; nm.amax_idx = kv->amax_idx; }
     if (m->fp8 && nparts > 0) PGV_TRY(gemv8(ctx, m, kv, GV_F32, m->q_head, m->s_head, kv->xn, H, kv->logits, V, V, B, s, &nm));
@@ -443,7 +446,7 @@ static int prefill_impl(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, const int32_t* h_i
     // lm_head only on the last position of every sequence (the reference computes all S positions, video_chatgpt.py:226)
     PGV_TRY(pgv_launch_gather_rows(resid, d_last, kv->resid, B, H, s));
     if (norm_fold_enabled()) {
-        PGV_TRY(pgv_launch_final_prep(m->dtype, kv->resid, m->norm_g, kv->xn, kv->ssq, B, H, s));
+        PGV_TRY(pgv_launch_final_prep(m->dtype, kv->resid, m->norm_g, kv->xn, kv->ssq, B, H, s, true));
         PGV_TRY(lm_head_and_pick(ctx, m, kv, B, -1, 0, s, 1));
     } else {
         PGV_TRY(pgv_launch_rmsnorm(m->dtype, kv->resid, m->norm_g, m->cfg.eps, kv->xn, B, H, s));
@@ -487,7 +490,7 @@ extern "C" int pgv_kv_truncate(pgv_kv* kv, int b, int len, void* stream) {
 static int decode_enqueue_unfolded(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int eos, int flags, hipStream_t s) {
     const int H = m->cfg.hidden, I = m->cfg.inter, heads = m->cfg.heads, B = kv->active, L = m->cfg.layers;
     pgv_prof_begin(ctx, 6, s);
-    PGV_TRY(pgv_launch_embed_tok_norm(m->dtype, kv->d_cur, m->embed, kv->resid, L > 0 ? m->layers[0].in_g : m->norm_g, kv->xn, kv->ssq, B, H, s));   // resid is what matters here
+    PGV_TRY(pgv_launch_embed_tok_norm(m->dtype, kv->d_cur, m->embed, kv->resid, L > 0 ? m->layers[0].in_g : m->norm_g, kv->xn, kv->ssq, B, H, s, false));   // resid is what matters here
     pgv_prof_end(ctx, 6, s, 0.0, 0.0);
     double kv_bytes = 0;
     for (int b = 0; b < B; ++b) kv_bytes += 2.0 * 2.0 * (double)(kv->h_len[b] + 1) * H;
@@ -514,7 +517,7 @@ static int decode_enqueue(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int eos, int fla
     // RMSNorm has no launch of its own in decode (GemvArgs, gemv.hip): the kernel that completes the residual also writes
     // xg = round16(resid * gamma_next) and sum-of-squares partials; the consumer GEMV scales its accumulators by rstd.
     pgv_prof_begin(ctx, 6, s);
-    PGV_TRY(pgv_launch_embed_tok_norm(m->dtype, kv->d_cur, m->embed, kv->resid, L > 0 ? m->layers[0].in_g : m->norm_g, kv->xn, kv->ssq, B, H, s));
+    PGV_TRY(pgv_launch_embed_tok_norm(m->dtype, kv->d_cur, m->embed, kv->resid, L > 0 ? m->layers[0].in_g : m->norm_g, kv->xn, kv->ssq, B, H, s, true));
     pgv_prof_end(ctx, 6, s, 0.0, 0.0);
     double kv_bytes = 0;
     for (int b = 0; b < B; ++b) kv_bytes += 2.0 * 2.0 * (double)(kv->h_len[b] + 1) * H;
@@ -522,11 +525,11 @@ static int decode_enqueue(pgv_ctx* ctx, pgv_llm* m, pgv_kv* kv, int eos, int fla
     for (int li = 0; li < L; ++li) {
         const LlmLayer& l = m->layers[li];
         const bool q8 = m->fp8;
-        GemvNorm cons; cons.ssq_in = kv->ssq; cons.nparts_in = parts_in; cons.hidden = H; cons.eps = m->cfg.eps; cons.ssq_ts = kv->ssq_ts;
+        GemvNorm cons; cons.ssq_in = kv->ssq; cons.nparts_in = parts_in; cons.hidden = H; cons.eps = m->cfg.eps; cons.ssq_ts = kv->ssq_ts; cons.x_blocked = true;
         if (q8) PGV_TRY(gemv8(ctx, m, kv, GV_STORE16, l.q_wqkv, l.s_wqkv, kv->xn, H, kv->qkv, 3 * H, 3 * H, B, s, &cons));
         else PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_STORE16, l.wqkv, kv->xn, H, kv->qkv, 3 * H, 3 * H, H, B, s, nullptr, &cons));
         PGV_TRY(pgv_launch_decode_attn(ctx, m->dtype, kv->qkv, kv->d_pos, m->rope, kv->Kc[li], kv->Vc[li], kv->ao, B, H, heads, kv->max_seq, kv_bytes, s, kv->dattn_part, kv->dattn_ticket));
-        GemvNorm prod; prod.gamma = l.post_g; prod.xg = kv->xn; prod.ssq_out = kv->ssq; prod.ssq_ts = kv->ssq_ts; prod.k8_part = kv->k8_part;
+        GemvNorm prod; prod.gamma = l.post_g; prod.xg = kv->xn; prod.ssq_out = kv->ssq; prod.ssq_ts = kv->ssq_ts; prod.k8_part = kv->k8_part; prod.x_blocked = true;
         if (q8) PGV_TRY(gemv8(ctx, m, kv, GV_RESIDNORM, l.q_wo, l.s_wo, kv->ao, H, kv->resid, H, H, B, s, &prod));
         else PGV_TRY(pgv_launch_gemv(ctx, m->dtype, GV_RESIDNORM, l.wo, kv->ao, H, kv->resid, H, H, H, B, s, nullptr, &prod));
         cons.nparts_in = nparts;

@@ -24,8 +24,9 @@ int pgv_launch_prefill_attn(pgv_ctx* ctx, int dtype, const void* qkv, void* out,
 int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void* x, int ldx, void* out, int ldo, int N, int K, int B, hipStream_t s,
                     const float* wscale = nullptr, const GemvNorm* norm = nullptr);
 int pgv_gemv_configure(pgv_ctx* ctx);      // per-device function attributes of the 8-phase producers: called once per context, outside graph capture
-int pgv_launch_embed_tok_norm(int dtype, const int* tok, const void* embed, float* resid, const float* gamma, void* xg, float* ssq, int B, int H, hipStream_t s);
-int pgv_launch_final_prep(int dtype, const float* resid, const float* gamma, void* xg, float* ssq, int B, int H, hipStream_t s);
+int pgv_launch_embed_tok_norm(int dtype, const int* tok, const void* embed, float* resid, const float* gamma, void* xg, float* ssq, int B, int H, hipStream_t s, bool x_blocked);
+int pgv_launch_final_prep(int dtype, const float* resid, const float* gamma, void* xg, float* ssq, int B, int H, hipStream_t s, bool x_blocked);
+int pgv_gemv_xblk_tiles(int B);            // column tiles of the blocked activation layout at B sequences (0: row-major)
 // fp8.hip
 int pgv_launch_quantize_fp8(int dtype, void* w16_blocked, void* w8_blocked, float* scales, long long N, long long K, hipStream_t s);
 int pgv_launch_unpack_blocked(int dtype, const void* src, float* dst, long long N, long long K, long long row_blk, long long blk_stride, long long row_off,

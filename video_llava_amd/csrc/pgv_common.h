@@ -183,4 +183,16 @@ struct GemvNorm {
     float* amax_val = nullptr; int* amax_idx = nullptr;      // f32 mode: per-workgroup greedy candidates [ceil(N / 16)][16]
     void* k8_part = nullptr;                                 // producer mode, batches beyond 16: scratch of the 8-phase form, [N / 16][8][B tiles][64] float4; null = 16-row kernel
     int ssq_ts = 0, amax_ts = 0;                             // batches beyond 16: the side arrays are tile-major [B / 16][...][16] with these tile strides (elements)
+    // batches beyond 16: the normalised 16-bit operand (consumer: x; producer: xg) is in the fragment-blocked ACTIVATION layout
+    // [K / 32][column tiles][4 k-groups][16 sequences][8 elements] (gv_xblk_offset): a consumer's MFMA B fragment is one contiguous 1 KiB wave-load
+    bool x_blocked = false;
 };
+
+// Byte offset of activation element (sequence b, feature n) in the fragment-blocked activation layout with `ct` column tiles of 16 sequences.
+// Four consecutive n (n % 4 == 0) of one sequence are 8 contiguous bytes, eight (n % 8 == 0) are 16.
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline size_t gv_xblk_offset(int b, int n, int ct) {
+    return ((((size_t)(n >> 5) * ct + (b >> 4)) * 4 + ((n & 31) >> 3)) * 16 + (b & 15)) * 16 + (size_t)(n & 7) * 2;
+}

@@ -88,6 +88,11 @@ def rccl_transport(cleanup: bool = True) -> dict:
     if not path:
         return out
     try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)      # RCCL writes through a buffered FILE*: flush every C stream of the process so that the lines are in the file
+    except Exception:                       # noqa: BLE001
+        pass
+    try:
         for cand in (path, path.replace("%h", os.uname().nodename).replace("%p", str(os.getpid()))):
             if os.path.exists(cand):
                 with open(cand, errors="replace") as f:
