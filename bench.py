@@ -27,6 +27,13 @@ import subprocess
 import sys
 import time
 
+if int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("PGV_RCCL_DEBUG_CAPTURE", "1") != "0" and "NCCL_DEBUG_FILE" not in os.environ:
+    # a rank of an N > 1 run: RCCL's INFO log goes to a per-process file BEFORE `import torch` loads librccl (it caches its debug level on first
+    # touch); `collective.transport` of the JSON line is parsed from it (video_llava_amd.parallel.rccl_transport)
+    import tempfile
+    os.environ["NCCL_DEBUG_FILE"] = os.path.join(tempfile.gettempdir(), "pgv_rccl_%h_%p.log")
+    os.environ["NCCL_DEBUG"] = "INFO"
+
 import numpy as np
 import torch
 

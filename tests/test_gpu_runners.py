@@ -428,6 +428,10 @@ torch.distributed.destroy_process_group()
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29613", PGV_DIST_FORCE_INIT="1",
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("PGV_DIST_BACKEND", None)
+    env.pop("NCCL_DEBUG_FILE", None)
+    from video_llava_amd import parallel as _par
+    _par.rccl_debug_env(env)                    # what bench.py sets before `import torch` for the ranks of an N > 1 run
+    assert env["NCCL_DEBUG"] == "INFO" and "%p" in env["NCCL_DEBUG_FILE"]
     r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and "ANSWERS" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
     line = r.stdout.split("ANSWERS", 1)[1].strip().splitlines()[0]                         # (RCCL prints its version banner to stdout at teardown)

@@ -100,26 +100,38 @@ template <typename T, int MODE, bool W8, int NW, int TL, int PU, bool X2, int CT
 __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
     constexpr int TILES = TL;
     static_assert(!X2 || CT == 1, "the merged x load uses the lanes of columns 8..15");
-    __shared__ f32x4_t red[NW][TILES * CT][64];
+    // HS (six row blocks and more): the weight stream is pipelined in HALF groups (one 32-column k-block per register buffer) -- a whole group of
+    // six row blocks x four column tiles would not fit the register file next to its 96 accumulator registers.  Same order of the MFMAs.
+    constexpr bool HS = (TL >= 6);
+    static_assert(!HS || (!W8 && PU == 1 && !X2), "half-group pipelining: 16-bit weights, one group per buffer");
+    static_assert(MODE != GV_RESIDNORM || TL == 1, "a residual producer owns one row block");
+    // The partial tiles of the NW waves meet in LDS, at most 16 tiles (128 KB) at a time: CTR column tiles per round.
+    constexpr int CTR = (TILES * CT <= 16) ? CT : (16 / TILES);
+    static_assert(CTR >= 1 && CT % CTR == 0, "column tiles per reduction round");
+    constexpr int RND = CT / CTR;
+    __shared__ f32x4_t red[NW][TILES * CTR][64];
     __shared__ f32x4_t ssq_red[NW][4 * CT];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kg = lane >> 4;
     const int kblocks = p.K >> 5;
-    int rb[TILES];
-    if constexpr (MODE == GV_SWIGLU) {
-        static_assert(TILES % 2 == 0, "SwiGLU: (gate, up) row-block pairs");
-#pragma unroll
-        for (int q = 0; q < TILES / 2; ++q) {                    // TILES / 2 output column blocks per workgroup, each a (gate, up) pair of row blocks
-            const int i0 = ((int)blockIdx.x * (TILES / 2) + q) * 16;
+    // row block of tile t.  SwiGLU: TILES / 2 output column blocks per workgroup, each a (gate, up) pair of row blocks; a ragged last workgroup
+    // (pair count not a multiple of TILES / 2) re-reads the last pair and stores nothing for it.
+    const int npairs = p.N >> 5;
+    auto rb_of = [&](int t) -> int {
+        if constexpr (MODE == GV_SWIGLU) {
+            static_assert(TILES % 2 == 0, "SwiGLU: (gate, up) row-block pairs");
+            const int i0 = min((int)blockIdx.x * (TILES / 2) + (t >> 1), npairs - 1) * 16;
             const int base = (i0 >> 5) * 64 + (i0 & 31);         // packed gate row (multiple of 16)
-            rb[2 * q] = base >> 4;                               // gate row block
-            rb[2 * q + 1] = (base + 32) >> 4;                    // matching up row block
+            return (base + (t & 1) * 32) >> 4;                   // gate row block / matching up row block
+        } else {
+            return (int)blockIdx.x * TILES + t;                  // may lie past the matrix in a ragged last workgroup (lm_head with 8 row blocks)
         }
-    } else {
+    };
+    const int nrb = (p.N + 15) >> 4;
+    int rb[TILES];                                               // the row block whose weights tile t STREAMS: clamped, a tile past the matrix stores nothing
 #pragma unroll
-        for (int t = 0; t < TILES; ++t) rb[t] = blockIdx.x * TILES + t;
-    }
+    for (int t = 0; t < TILES; ++t) rb[t] = min(rb_of(t), nrb - 1);
     // folded RMSNorm, consumer side: this thread's share of the sum-of-squares partials (L2 hits), requested before the weight stream
     // (three independent loads whose first USE is after the weight loop: summing them here would park the wave on an L2 round trip
     // before its first weight load -- measured +1.4 us on the 18 us qkv GEMV)
@@ -137,11 +149,11 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
             for (int q = 0; q < SSQ_LD; ++q) ssq_ld[ct][q] = ((const f32x4_t*)(p.ssq_in + (size_t)ct * p.ssq_ts))[min(tid + q * NW * 64, n4 - 1)];   // chunk (= 4 batch columns) index & 3 is fixed per thread
     }
     // producer side: the old residual and gamma are requested up front as well (by every wave; wave 0 consumes them in the epilogue)
-    f32x4_t r_old[CT], g_nx = {0.f, 0.f, 0.f, 0.f};
+    // (wave w finishes column tile w in the epilogue: it requests that tile's old residual only)
+    f32x4_t r_old = {0.f, 0.f, 0.f, 0.f}, g_nx = {0.f, 0.f, 0.f, 0.f};
     if constexpr (MODE == GV_RESIDNORM) {
         const int n0p = blockIdx.x * 16 + kg * 4;
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) r_old[ct] = *(const f32x4_t*)(p.out + ((size_t)min(ct * 16 + l15, p.B - 1) * p.ldo + n0p) * 4);
+        r_old = *(const f32x4_t*)(p.out + ((size_t)min(min(w, CT - 1) * 16 + l15, p.B - 1) * p.ldo + n0p) * 4);
         g_nx = *(const f32x4_t*)(p.gamma + n0p);
     }
     // x fragment (MFMA B operand: lane = batch column l15, 8 consecutive k): an MFMA tile has 16 batch columns; the lanes of the columns
@@ -164,7 +176,64 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
     for (int t = 0; t < TILES; ++t)
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) acc[t][ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    {
+    if constexpr (HS) {
+        // steps i = 0, 1, ...: step i is k-block h = i & 1 of this wave's group w + NW * (i >> 1); every wave runs 2 * ceil(groups / NW) steps, a
+        // step past the end of K re-reads the last k-block against an all-zero x fragment (exact zeros, as below).
+        const int kb_end = kblocks, j_end = (kb_end + 1) >> 1;
+        const int nsteps = 2 * ((j_end + NW - 1) / NW);
+        const char* wp[TILES];
+#pragma unroll
+        for (int t = 0; t < TILES; ++t) wp[t] = p.W + ((size_t)rb[t] * kblocks) * 1024 + lane * 16;
+        auto loadh = [&](typename T::v8 (&wf)[TILES], typename T::v8 (&xf)[CT], int i) {
+            const int kb = min(2 * (w + NW * (i >> 1)) + (i & 1), kb_end - 1);
+            if (!GV_ABL(p, 4)) {
+#pragma unroll
+                for (int t = 0; t < TILES; ++t) wf[t] = __builtin_nontemporal_load((const typename T::v8*)(wp[t] + (size_t)kb * 1024));
+            }
+            if (!GV_ABL(p, 1)) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) xf[ct] = xload((size_t)kb, ct);
+            }
+        };
+        auto mmah = [&](typename T::v8 (&wf)[TILES], typename T::v8 (&xf)[CT], int i, bool last) {
+            typename T::v8 xv[CT];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) xv[ct] = xf[ct];
+            if (last) {
+                const typename T::v8 z = {};
+                const bool past = 2 * (w + NW * (i >> 1)) + (i & 1) >= kb_end;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) xv[ct] = past ? z : xv[ct];
+            }
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) {
+                if (GV_ABL(p, 2)) {
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) acc[t][ct][0] += (float)wf[t][0] + (float)xv[ct][0];
+                    continue;
+                }
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) acc[t][ct] = T::mfma16(wf[t], xv[ct], acc[t][ct]);
+            }
+        };
+        typename T::v8 wa[TILES] = {}, wb[TILES] = {}, xa[CT] = {}, xb[CT] = {};
+        loadh(wa, xa, 0);
+        int i = 0;
+        for (; i + 2 < nsteps; i += 2) {                          // the last two steps are the only ones that can lie past the end of K
+            loadh(wb, xb, i + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mmah(wa, xa, i, false);
+            __builtin_amdgcn_sched_barrier(0);
+            loadh(wa, xa, i + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mmah(wb, xb, i + 1, false);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        loadh(wb, xb, i + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mmah(wa, xa, i, true);
+        mmah(wb, xb, i + 1, true);
+    } else {
         // groups (64 columns) j_lo + w + NW * g, g = 0 .. : batch b holds g = b * PU .. b * PU + PU - 1.  Every batch but the last is complete
         // for every wave (the waves' group counts differ by at most one); in the last batch, entries past the end re-read the last valid
         // block (an L2 hit) against an all-zero x fragment, which adds exact zeros -- no predicated loads (predicated loads would make hipcc serialise the whole batch: a vmcnt(0) per load).
@@ -265,10 +334,6 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
             mma(wa, xa, i, true);
         }
     }
-#pragma unroll
-    for (int t = 0; t < TILES; ++t)
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct) red[w][t * CT + ct][lane] = acc[t][ct];
     if (SSQ_LATE && scaled) {
         const int n4 = p.nparts_in * 4;
 #pragma unroll
@@ -297,85 +362,98 @@ __global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
         if (lane >= 48 && lane < 52) ssq_red[w][ct * 4 + lane - 48] = ssq_acc;
       }
     }
-    __syncthreads();
-    if (w != 0) return;
+    // Cross-wave reduction + epilogue (round 6: spread over the waves).  Every (tile, column tile) unit -- a (gate, up) tile pair for SwiGLU -- is
+    // summed over the waves in wave order and finished by ONE wave, unit u by wave u % NW (until round 5 wave 0 did all of them, up to 16 tiles of
+    // 8 KB, while the other seven waves had already left: a serial tail on every launch).  The order of the additions inside a unit is unchanged.
+    constexpr int UPT = (MODE == GV_SWIGLU) ? TILES / 2 : TILES;       // units per column tile
+    auto tile_sum = [&](int t, int ctl) -> f32x4_t {
+        f32x4_t tot = red[0][t * CTR + ctl][lane];
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {                             // one pass of the 16-column epilogue per column tile
-    f32x4_t tot[TILES];
+        for (int ww = 1; ww < NW; ++ww) tot += red[ww][t * CTR + ctl][lane];
+        return tot;
+    };
 #pragma unroll
-    for (int t = 0; t < TILES; ++t) {
-        tot[t] = red[0][t * CT + ct][lane];
-#pragma unroll
-        for (int ww = 1; ww < NW; ++ww) tot[t] += red[ww][t * CT + ct][lane];
-    }
-    if constexpr (W8) {                                           // per-row power-of-two scale: exact in fp32
-#pragma unroll
-        for (int t = 0; t < TILES; ++t) tot[t] *= *(const f32x4_t*)(p.wscale + rb[t] * 16 + kg * 4);
-    }
-    // lane holds D[n = kg*4 + r][b = ct*16 + l15]
-    const int b = ct * 16 + l15;
-    if (scaled) {
-        float ss = 0.f;
-#pragma unroll
-        for (int ww = 0; ww < NW; ++ww) ss += ssq_red[ww][ct * 4 + (l15 >> 2)][l15 & 3];       // fixed order: deterministic
-        const float rstd = rsqrtf(ss * p.inv_h + p.eps);
-#pragma unroll
-        for (int t = 0; t < TILES; ++t) tot[t] *= rstd;
-    }
-    const int n0 = (MODE == GV_SWIGLU ? (int)blockIdx.x : rb[0]) * 16 + kg * 4;
-    if constexpr (MODE == GV_RESIDNORM) {
-        // r = resid + y (fp32, written back); xg = round16(r * gamma); sum of r^2 over this workgroup's 16 rows per batch column
-        float sq = 0.f;
-        if (b < p.B) {
-            f32x4_t* rp = (f32x4_t*)(p.out + ((size_t)b * p.ldo + n0) * 4);
-            const f32x4_t r = r_old[ct] + tot[0];
-            *rp = r;
-            const f32x4_t g = g_nx;
-            *(u32x2_t*)(p.xg + (p.xgblk ? gv_xblk_offset(b, n0, CT) : ((size_t)b * p.ldo + n0) * 2)) = pack4<T>(r[0] * g[0], r[1] * g[1], r[2] * g[2], r[3] * g[3]);
-            sq = (r[0] * r[0] + r[1] * r[1]) + (r[2] * r[2] + r[3] * r[3]);
-        }
-        {   // sum over the four rows of 16 lanes (the 16 output rows of this workgroup) without LDS round trips
-            sq = rows_sum_to_row3(sq);
-        }
-        if (kg == 3) p.ssq_out[(size_t)ct * p.ssq_ts + (size_t)blockIdx.x * 16 + l15] = sq;               // columns >= B carry 0
-        continue;
-    }
-    if constexpr (MODE == GV_F32) {
-        if (p.amax_val != nullptr) {                              // wave-uniform
-            float bv = -INFINITY; int bi = 0x7fffffff;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { const float v = tot[0][r]; if (n0 + r < p.N && v > bv) { bv = v; bi = n0 + r; } }      // ascending n: the first maximum wins, NaN never does
-#pragma unroll
-            for (int o = 16; o <= 32; o <<= 1) {
-                const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
-                if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-            }
-            if (kg == 0) { p.amax_val[(size_t)ct * p.amax_ts + (size_t)blockIdx.x * 16 + l15] = bv; p.amax_idx[(size_t)ct * p.amax_ts + (size_t)blockIdx.x * 16 + l15] = bi; }
-        }
-    }
-    if (b >= p.B) continue;
-    if constexpr (MODE == GV_SWIGLU) {
-#pragma unroll
-        for (int q = 0; q < TILES / 2; ++q) {
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { const float g = tot[2 * q][r]; v[r] = g * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(g * -1.4426950408889634f)) * tot[2 * q + 1][r]; }   // same SiLU as gemm.hip
-            *(u32x2_t*)(p.out + ((size_t)b * p.ldo + ((int)blockIdx.x * (TILES / 2) + q) * 16 + kg * 4) * 2) = pack4<T>(v[0], v[1], v[2], v[3]);
-        }
-    } else if constexpr (MODE == GV_STORE16) {
+    for (int r = 0; r < RND; ++r) {
+        if (r > 0) __syncthreads();                               // the previous round's tiles have been read
 #pragma unroll
         for (int t = 0; t < TILES; ++t)
-            *(u32x2_t*)(p.out + ((size_t)b * p.ldo + n0 + t * 16) * 2) = pack4<T>(tot[t][0], tot[t][1], tot[t][2], tot[t][3]);
-    } else if constexpr (MODE == GV_RESID) {
-        f32x4_t* rp = (f32x4_t*)(p.out + ((size_t)b * p.ldo + n0) * 4);
-        *rp = *rp + tot[0];
-    } else {
-        float* op = (float*)p.out + (size_t)b * p.ldo + n0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (n0 + r < p.N) op[r] = tot[0][r];
+            for (int ctl = 0; ctl < CTR; ++ctl) red[w][t * CTR + ctl][lane] = acc[t][r * CTR + ctl];
+        __syncthreads();
+        for (int u = w; u < UPT * CTR; u += NW) {                 // wave-uniform
+            const int ut = u / CTR, ctl = u - ut * CTR, ct = r * CTR + ctl;
+            const int b = ct * 16 + l15;                          // lane holds D[n = kg*4 + r][b]
+            float rstd = 1.f;
+            if (scaled) {
+                float ss = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < NW; ++ww) ss += ssq_red[ww][ct * 4 + (l15 >> 2)][l15 & 3];       // fixed order: deterministic
+                rstd = rsqrtf(ss * p.inv_h + p.eps);
+            }
+            if constexpr (MODE == GV_SWIGLU) {
+                const int pair = (int)blockIdx.x * (TILES / 2) + ut;
+                f32x4_t tg = tile_sum(2 * ut, ctl), tu = tile_sum(2 * ut + 1, ctl);
+                if constexpr (W8) {                               // per-row power-of-two scale: exact in fp32
+                    tg *= *(const f32x4_t*)(p.wscale + rb_of(2 * ut) * 16 + kg * 4);
+                    tu *= *(const f32x4_t*)(p.wscale + rb_of(2 * ut + 1) * 16 + kg * 4);
+                }
+                if (scaled) { tg *= rstd; tu *= rstd; }
+                if (b < p.B && pair < npairs) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float g = tg[e]; v[e] = g * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(g * -1.4426950408889634f)) * tu[e]; }   // same SiLU as gemm.hip
+                    *(u32x2_t*)(p.out + ((size_t)b * p.ldo + pair * 16 + kg * 4) * 2) = pack4<T>(v[0], v[1], v[2], v[3]);
+                }
+            } else {
+                const int rbt = rb_of(ut);
+                if (rbt >= nrb) continue;                         // wave-uniform: a tile past the matrix (ragged last workgroup)
+                const int n0 = rbt * 16 + kg * 4;
+                f32x4_t tot = tile_sum(ut, ctl);
+                if constexpr (W8) tot *= *(const f32x4_t*)(p.wscale + rbt * 16 + kg * 4);
+                if (scaled) tot *= rstd;
+                if constexpr (MODE == GV_RESIDNORM) {
+                    // r = resid + y (fp32, written back); xg = round16(r * gamma); sum of r^2 over this workgroup's 16 rows per batch column
+                    float sq = 0.f;
+                    if (b < p.B) {
+                        f32x4_t* rp = (f32x4_t*)(p.out + ((size_t)b * p.ldo + n0) * 4);
+                        const f32x4_t rr = r_old + tot;           // (wave w == unit ct: its r_old is this tile's)
+                        *rp = rr;
+                        const f32x4_t g = g_nx;
+                        *(u32x2_t*)(p.xg + (p.xgblk ? gv_xblk_offset(b, n0, CT) : ((size_t)b * p.ldo + n0) * 2)) = pack4<T>(rr[0] * g[0], rr[1] * g[1], rr[2] * g[2], rr[3] * g[3]);
+                        sq = (rr[0] * rr[0] + rr[1] * rr[1]) + (rr[2] * rr[2] + rr[3] * rr[3]);
+                    }
+                    sq = rows_sum_to_row3(sq);                    // the four rows of 16 lanes (the 16 output rows of this workgroup), no LDS round trips
+                    if (kg == 3) p.ssq_out[(size_t)ct * p.ssq_ts + (size_t)blockIdx.x * 16 + l15] = sq;               // columns >= B carry 0
+                    continue;
+                }
+                if constexpr (MODE == GV_F32) {
+                    if (p.amax_val != nullptr) {                  // wave-uniform
+                        float bv = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { const float v = tot[e]; if (n0 + e < p.N && v > bv) { bv = v; bi = n0 + e; } }      // ascending n: the first maximum wins, NaN never does
+#pragma unroll
+                        for (int o = 16; o <= 32; o <<= 1) {
+                            const float ov = __shfl_xor(bv, o, 64); const int oi = __shfl_xor(bi, o, 64);
+                            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                        }
+                        if (kg == 0) { p.amax_val[(size_t)ct * p.amax_ts + (size_t)rbt * 16 + l15] = bv; p.amax_idx[(size_t)ct * p.amax_ts + (size_t)rbt * 16 + l15] = bi; }
+                    }
+                }
+                if (b >= p.B) continue;
+                if constexpr (MODE == GV_STORE16) {
+                    *(u32x2_t*)(p.out + ((size_t)b * p.ldo + n0) * 2) = pack4<T>(tot[0], tot[1], tot[2], tot[3]);
+                } else if constexpr (MODE == GV_RESID) {
+                    f32x4_t* rp = (f32x4_t*)(p.out + ((size_t)b * p.ldo + n0) * 4);
+                    *rp = *rp + tot;
+                } else if constexpr (MODE == GV_F32) {
+                    float* op = (float*)p.out + (size_t)b * p.ldo + n0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n0 + e < p.N) op[e] = tot[e];
+                }
+            }
+        }
     }
-    }   // column tiles
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -656,8 +734,11 @@ struct GemvShape {
 };
 template <int MODE, int TL, int CT>
 constexpr GemvShape gemv_shape() {
-    return {MODE, TL, CT, {{&launch_variant<MODE, false, TL, gemv_pu(TL, false, CT), false, CT>, x2_variant<MODE, false, TL, CT>()},
-                           {&launch_variant<MODE, true, TL, gemv_pu(TL, true, CT), false, CT>, x2_variant<MODE, true, TL, CT>()}}};
+    if constexpr (TL >= 6)                       // half-group pipelining: 16-bit weights only (an fp8 group is ONE load per lane), wide batches only
+        return {MODE, TL, CT, {{&launch_variant<MODE, false, TL, 1, false, CT>, nullptr}, {nullptr, nullptr}}};
+    else
+        return {MODE, TL, CT, {{&launch_variant<MODE, false, TL, gemv_pu(TL, false, CT), false, CT>, x2_variant<MODE, false, TL, CT>()},
+                               {&launch_variant<MODE, true, TL, gemv_pu(TL, true, CT), false, CT>, x2_variant<MODE, true, TL, CT>()}}};
 }
 static const GemvShape kGemvShapes[] = {
     // one MFMA tile of sequences (B <= 16)
@@ -665,9 +746,9 @@ static const GemvShape kGemvShapes[] = {
     gemv_shape<GV_F32, 1, 1>(), gemv_shape<GV_RESIDNORM, 1, 1>(),
     // 2 / 4 column tiles (B <= 32 / 64)
     gemv_shape<GV_STORE16, 1, 2>(), gemv_shape<GV_STORE16, 3, 2>(), gemv_shape<GV_RESID, 1, 2>(), gemv_shape<GV_SWIGLU, 2, 2>(), gemv_shape<GV_SWIGLU, 4, 2>(),
-    gemv_shape<GV_F32, 1, 2>(), gemv_shape<GV_RESIDNORM, 1, 2>(),
+    gemv_shape<GV_SWIGLU, 6, 2>(), gemv_shape<GV_F32, 1, 2>(), gemv_shape<GV_F32, 8, 2>(), gemv_shape<GV_RESIDNORM, 1, 2>(),
     gemv_shape<GV_STORE16, 1, 4>(), gemv_shape<GV_STORE16, 3, 4>(), gemv_shape<GV_RESID, 1, 4>(), gemv_shape<GV_SWIGLU, 2, 4>(), gemv_shape<GV_SWIGLU, 4, 4>(),
-    gemv_shape<GV_F32, 1, 4>(), gemv_shape<GV_RESIDNORM, 1, 4>(),
+    gemv_shape<GV_SWIGLU, 6, 4>(), gemv_shape<GV_F32, 1, 4>(), gemv_shape<GV_F32, 8, 4>(), gemv_shape<GV_RESIDNORM, 1, 4>(),
 };
 
 // The 8-phase form of a residual producer with CT column tiles and NWB row blocks (= waves) per workgroup; `a` is complete except lds_bytes.
@@ -722,6 +803,14 @@ static GemvChoice choose_gemv(int mode, bool w8, int B, int grid, int K, int num
         if (mode == GV_STORE16 && grid % 3 == 0) c.tl = 3;
         // (four column tiles: 228 VGPRs once the sum-of-squares partials are requested after the weight loop, SSQ_LATE)
         if (mode == GV_SWIGLU) c.tl = (grid % 2 == 0 && (B <= 32 || lab_switch("PGV_GEMV_WIDE_TL4", 1) != 0)) ? 4 : 2;
+        // A wide workgroup holds a CU to itself (its registers and the LDS of its partial tiles), so the launch runs in ROUNDS of num_cu workgroups
+        // and every workgroup moves the whole activation operand through its CU: 7B gate/up = 688 (gate, up) pairs -> 344 workgroups of two pairs =
+        // two rounds (88 CUs run a second workgroup, the others wait: 50.9 us at 64 sequences), 230 workgroups of THREE pairs = one round and a third
+        // fewer reads of x (LAB.md round 6).  Taken when three pairs per workgroup fit one round and two do not.
+        if (mode == GV_SWIGLU && !w8 && lab_switch("PGV_GEMV_WIDE_TL6", 1) != 0 && (grid + 2) / 3 <= num_cu && (grid + 1) / 2 > num_cu) c.tl = 6;
+        // lm_head: 2001 row blocks; one per workgroup means 2001 passes over the activation operand (512 KB each against 128 KB of weights: 102 us at
+        // 64 sequences).  Eight per workgroup: 251 workgroups, one round.
+        if (mode == GV_F32 && !w8 && lab_switch("PGV_GEMV_WIDE_HEAD8", 1) != 0 && (grid + 7) / 8 <= num_cu) c.tl = 8;
         // narrow matrices (o_proj, down_proj): 8 row blocks x K phase per workgroup + a finish launch where it pays (kernel trace at 32 clips:
         // down_proj 32.0 -> 22.4 + 4.9 us (finish), o_proj 13.3 -> 9.6 + 4.9: the short-K matrix only gains once the batch spans four tiles)
         if (mode == GV_RESIDNORM) c.k8 = k8_ok && (K / 64) >= 16 && (B > 32 || K >= 8192);
@@ -771,8 +860,8 @@ int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void
         a.ssq_in = norm->ssq_in; a.nparts_in = norm->nparts_in; a.inv_h = 1.0f / (float)norm->hidden; a.eps = norm->eps;
         a.gamma = norm->gamma; a.xg = (char*)norm->xg; a.ssq_out = norm->ssq_out; a.amax_val = norm->amax_val; a.amax_idx = norm->amax_idx;
         if (norm->x_blocked && pgv_gemv_xblk_tiles(B) > 0) {          // consumers read x blocked, producers write xg blocked
-            PGV_CHECK(K % 32 == 0 && N % 32 == 0, "gemv: the blocked activation layout needs K and N in multiples of 32");
-            if (mode == GV_RESIDNORM) a.xgblk = 1; else a.xblk = 1;
+            if (mode == GV_RESIDNORM) { PGV_CHECK(N % 32 == 0, "gemv: a blocked xg needs N in multiples of 32"); a.xgblk = 1; }
+            else a.xblk = 1;                                       // (K % 32 == 0 is checked above)
         }
         PGV_CHECK(norm->nparts_in * 4 <= 3 * 8 * 64, "gemv: %d sum-of-squares partials exceed what a consumer workgroup loads (hidden <= 6144)", norm->nparts_in);
     }
@@ -792,7 +881,9 @@ int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void
             if (g.mode == mode && g.tl == c.tl && g.ct == c.ct) { shape = &g; break; }
         PGV_CHECK(shape != nullptr, "gemv: no kernel for mode %d with %d row blocks x %d column tiles", mode, c.tl, c.ct);
         const int tiles_per_wg = mode == GV_SWIGLU ? c.tl / 2 : c.tl;       // SwiGLU: the grid counts (gate, up) pairs
-        PGV_TRY(shape->fn[w8][c.x2 && c.ct == 1](dtype, grid / tiles_per_wg, a, s));
+        gemv_launch_fn fn = shape->fn[w8][c.x2 && c.ct == 1];
+        PGV_CHECK(fn != nullptr, "gemv: mode %d with %d row blocks x %d column tiles has no %s kernel", mode, c.tl, c.ct, w8 ? "fp8" : "16-bit");
+        PGV_TRY(fn(dtype, (grid + tiles_per_wg - 1) / tiles_per_wg, a, s));     // (only the three-pair SwiGLU shape can leave a ragged last workgroup)
     }
     pgv_prof_end(ctx, 3, s, 2.0 * B * (double)N * K, (w8 ? 1.0 : 2.0) * (double)N * K);
     return PGV_OK;

@@ -68,14 +68,27 @@ def _arm_rccl_debug_capture():
     ("Channel 00/0 : 0[0] -> 1[1] via P2P/IPC ...", "... via SHM ...", "... via NET/Socket ...") are what rccl_transport() counts."""
     global _rccl_debug_file
     if os.environ.get("PGV_RCCL_DEBUG_CAPTURE", "1") == "0" or "NCCL_DEBUG_FILE" in os.environ:
-        _rccl_debug_file = os.environ.get("NCCL_DEBUG_FILE")
+        _rccl_debug_file = os.environ.get("NCCL_DEBUG_FILE")         # set by rccl_debug_env() before the interpreter loaded librccl, or by the user
         return
     import tempfile
     fd, path = tempfile.mkstemp(prefix=f"pgv_rccl_{os.getpid()}_", suffix=".log")
     os.close(fd)
     os.environ["NCCL_DEBUG_FILE"] = path
-    os.environ.setdefault("NCCL_DEBUG", "INFO")
+    os.environ["NCCL_DEBUG"] = "INFO"
     _rccl_debug_file = path
+
+
+def rccl_debug_env(env: dict | None = None) -> dict:
+    """The two variables that make RCCL write its INFO log to a per-process file, as a dict to merge into a child's environment -- or, with
+    env=None, applied to THIS process (call it before `import torch`: RCCL caches its debug level the first time the library is touched, which
+    `import torch` already does -- setting the variables in init_distributed was too late on the MI355X box, gpurun_out/r6c).  Respects what the
+    user already set."""
+    target = os.environ if env is None else env
+    if target.get("PGV_RCCL_DEBUG_CAPTURE", "1") != "0" and "NCCL_DEBUG_FILE" not in target:
+        import tempfile
+        target["NCCL_DEBUG_FILE"] = os.path.join(tempfile.gettempdir(), "pgv_rccl_%h_%p.log")
+        target["NCCL_DEBUG"] = "INFO"          # the channel lines are INFO level (the pool's boxes export NCCL_DEBUG=WARN); PGV_RCCL_DEBUG_CAPTURE=0 leaves both alone
+    return target
 
 
 def rccl_transport(cleanup: bool = True) -> dict:
@@ -106,7 +119,7 @@ def rccl_transport(cleanup: bool = True) -> dict:
                             out["net"] += 1
                         if "XGMI" in line.upper():
                             out["xgmi_mentions"] += 1
-                if cleanup and cand.startswith(os.path.join(os.path.dirname(cand), "pgv_rccl_")):
+                if cleanup and os.path.basename(cand).startswith("pgv_rccl_"):
                     try:
                         os.remove(cand)
                     except OSError:
