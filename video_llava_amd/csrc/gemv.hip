@@ -544,8 +544,9 @@ __global__ __launch_bounds__(NWB * 64) void gemv_k8_kernel(GemvArgs p, f32x4_t* 
             // LDS-DMA (round 6): one wave-instruction lands 8 rows x 128 B = 1 KiB linearly in LDS, every lane fetching the 16-byte chunk that
             // belongs at its position (the XOR swizzle is applied on the SOURCE side); all instructions of a pass are in flight together.  (The
             // first version loaded 16 bytes per thread into a register and stored it, an L2 round trip per loop iteration: 12 dependent
-            // iterations per pass at four column tiles -- most of the kernel's time at 64 sequences.)  Rows >= B re-read the last sequence:
-            // their tile columns are never stored.
+            // iterations per pass at four column tiles -- 18.5 -> 15.2 us per launch at 64 sequences.)  Rows >= B re-read the last sequence:
+            // their tile columns are never stored.  (Staging the next pass behind the running one -- two half buffers, the DMA issued by inline
+            // asm so that hipcc does not drain the weight prefetch in front of every fragment read -- was built and measured: no gain, 15.3 us.)
             const int srow = lane >> 3, pos = lane & 7;
             for (int q = w; q < ng * Brows / 8; q += NWB) {
                 const int fr = q * 8 + srow, gi = fr / Brows, row = fr - gi * Brows;
