@@ -40,7 +40,12 @@ def test_release_library_reads_five_switches_and_the_split_merge_lowers_to_sc1()
     names = set(re.findall(rb"\x00(PGV_[A-Z0-9_]{3,})\x00", data))        # NUL-delimited C strings: getenv names (PGV_F16 ... inside messages are not)
     assert names == {b"PGV_DATTN_SPLIT", b"PGV_LLM_NORM_FOLD", b"PGV_NO_GRAPH", b"PGV_VIT_LANES", b"PGV_VIT_LN_FOLD"}, names
     found = build.check_isa()
-    assert len(found) == 6 and all(v["cache_maintenance"] == 0 and v["atomics"] == 1 for v in found.values())
+    split = {k: v for k, v in found.items() if k[0] != "vit_attn"}
+    assert len(split) == 6 and all(v["cache_maintenance"] == 0 and v["atomics"] == 1 for v in split.values())
+    # ... and the two pieces of inline asm of the ViT attention kernel still assemble as written: the half swap keeps its wait state,
+    # every LDS-DMA sits directly behind the s_mov_b32 m0 that belongs to it
+    attn = {k: v for k, v in found.items() if k[0] == "vit_attn"}
+    assert len(attn) == 4 and all(v["half_swaps_with_wait_state"] >= 2 and v["lds_dma"] == v["lds_dma_with_m0"] >= 2 for v in attn.values()), attn
 
 
 def test_product_path_fails_loudly_without_gpu():

@@ -160,7 +160,42 @@ def check_isa() -> dict:
                                "compiler's lowering -- set PGV_DATTN_SPLIT=1 and fix csrc/decode_attn.hip")
     if len(found) != 6:
         raise RuntimeError(f"check_isa: expected 6 instantiations of decode_attn_split_kernel (2 dtypes x splits 2/4/8), found {sorted(found)}")
+    found.update(_check_isa_vit_attn())
     return found
+
+
+def _check_isa_vit_attn() -> dict:
+    """Second place that leans on hand-placed ISA: csrc/vit_attn.hip's half_swap wraps v_permlane32_swap_b32 in inline asm with its own
+    wait state (`s_nop 1`: the hazard recognizer cannot see inside inline asm, and the first version without it returned wrong maxima at N = 5),
+    and the K / V staging issues global_load_lds by inline asm with M0 set in the same statement.  Requires, in every instantiation of
+    vit_attn_kernel: every v_permlane32_swap_b32 that comes from the inline asm is directly preceded by an s_nop of at least 1, and every
+    global_load_lds_dwordx4 is directly preceded by the s_mov_b32 m0 that belongs to it (nothing scheduled in between)."""
+    import re
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "vit_attn.s")
+        r = subprocess.run([_hipcc(), *[f for f in FLAGS if f != "-fPIC"], *EXTRA_FLAGS.get("vit_attn.hip", []), "--cuda-device-only", "-S",
+                            os.path.join(CSRC, "vit_attn.hip"), "-o", out], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"check_isa: hipcc -S failed:\n{r.stderr}")
+        text = open(out).read()
+    res = {}
+    for m in re.finditer(r"^(_ZN\S*vit_attn_kernelI(\w+?)Li0ELi(\d)E\S*):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
+        name, dt, nw, body = m.group(1), m.group(2), int(m.group(3)), m.group(4)
+        ins = [ln.strip() for ln in body.split("\n") if ln.strip() and not ln.strip().startswith((";", ".", "//"))]
+        swaps = [i for i, ln in enumerate(ins) if ln.startswith("v_permlane32_swap_b32")]
+        guarded = [i for i in swaps if i > 0 and re.match(r"s_nop\s+([1-9]\d*)", ins[i - 1])]
+        dmas = [i for i, ln in enumerate(ins) if ln.startswith("global_load_lds_dwordx4")]
+        m0ok = [i for i in dmas if i > 0 and ins[i - 1].startswith("s_mov_b32 m0,")]
+        res[("vit_attn", dt, nw)] = dict(half_swaps=len(swaps), half_swaps_with_wait_state=len(guarded), lds_dma=len(dmas), lds_dma_with_m0=len(m0ok))
+        # the asm half swaps (maxima + row sums; the output transposition uses the builtin, whose hazards the compiler handles) must keep their nop
+        if len(guarded) < 2 or len(dmas) < 2 or len(m0ok) != len(dmas):
+            raise RuntimeError(f"check_isa: {name}: {len(guarded)} of {len(swaps)} v_permlane32_swap_b32 directly behind an s_nop >= 1 (need >= 2), "
+                               f"{len(m0ok)} of {len(dmas)} global_load_lds_dwordx4 directly behind their s_mov_b32 m0 (need all, >= 2): the inline asm of "
+                               "csrc/vit_attn.hip no longer assembles the way it was written")
+    if len(res) != 4:
+        raise RuntimeError(f"check_isa: expected 4 instantiations of vit_attn_kernel (2 dtypes x 4 / 8 waves), found {sorted(res)}")
+    return res
 
 
 if __name__ == "__main__":

@@ -193,9 +193,7 @@ extern "C" int pgv_vit_forward(pgv_ctx* ctx, pgv_vit* v, const void* d_pixels, i
     for (int k = 0, at = 0; k < lanes; ++k) { lane_t0[k] = at; lane_T[k] = (T - at + (lanes - k) - 1) / (lanes - k); at += lane_T[k]; }
     int chunk_frames = v->max_chunk_frames;
 #ifdef PGV_LAB
-#ifdef PGV_LAB
     { static int c = -1; if (c < 0) { const char* e = getenv("PGV_VIT_CHUNK"); c = e ? atoi(e) : 0; } if (c > 0) chunk_frames = c; }   // lab: frames per lane and pass
-#endif
 #endif
     // the arena holds `lanes` workspaces: a lane's pass is capped at chunk_frames / lanes so the total stays what one lane of chunk_frames took
     // (with T > max_chunk_frames the arena would otherwise double next to a 13B model + KV cache)

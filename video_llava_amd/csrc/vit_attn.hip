@@ -116,28 +116,51 @@ __global__ __launch_bounds__(NWAVES * 64) void vit_attn_kernel(AttnArgs p) {
     // (conflict-free ds_read_b128 of one row per lane); V: chunk ^ (((row >> 1) & 1) << 2) (conflict-free transposing reads: the 32 lanes of
     // an LDS cycle touch 4 consecutive keys x 64 B, and rows two apart share banks).  Rows past N re-read the last row: their
     // probabilities are exactly 0 and the duplicated V values are finite.
-#ifndef PGV_LAB_ATTN_AUX
-#define PGV_LAB_ATTN_AUX 0              // cache-policy bits of the K / V staging loads (every byte is read once, by one workgroup): lab A/B
+    // The DMA is issued by inline asm (M0 = LDS destination of the wave-instruction; nothing else in this kernel uses M0: gfx9 DS instructions
+    // do not read it).  With __builtin_amdgcn_global_load_lds hipcc puts s_waitcnt vmcnt(0) in front of the V fragment reads of EVERY chunk while
+    // a DMA may be pending (it cannot tell the rows a pending DMA writes from the rows a chunk reads), which would end the overlap below at the
+    // first chunk and drain the Q prefetch and the output stores in every later one.  The waits that order DMA and reads are explicit.
+#ifndef PGV_LAB_ATTN_SPLIT
+#define PGV_LAB_ATTN_SPLIT 3           // lab A/B: chunks of the first staging part where one workgroup owns the CU; 0 = one part
 #endif
-    {
+#ifndef PGV_LAB_ATTN_ASMDMA
+#define PGV_LAB_ATTN_ASMDMA 1          // lab A/B: 0 = __builtin_amdgcn_global_load_lds (only sensible with one staging part)
+#endif
+    auto dma16 = [&](const char* src, const char* dst) {
+#if !PGV_LAB_ATTN_ASMDMA
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        return;
+#endif
+        asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"((unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)dst) : "memory");
+    };
+    auto stage = [&](int g_lo, int g_hi) {
         const int srow = lane >> 3, slot = lane & 7;
-        for (int g = w; g < npad / 8; g += nw) {
+        for (int g = g_lo + w; g < g_hi; g += nw) {
             const int row = g * 8 + srow;
             const int rr = min(row, N - 1);
-            if (!(PGV_ATTN_ABL(p) & 4)) {
-                const int chunk = slot ^ ((row >> 1) & 7);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + ((row0 + rr) * p.ld + chunk * 8) * 2),
-                                                 (__attribute__((address_space(3))) void*)(Ks + g * 1024), 16, 0, PGV_LAB_ATTN_AUX);
-            }
-            if (!(PGV_ATTN_ABL(p) & 1)) {
-                const int chunk = slot ^ (((row >> 1) & 1) << 2);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + ((row0 + rr) * p.ld + chunk * 8) * 2),
-                                                 (__attribute__((address_space(3))) void*)(Vs + g * 1024), 16, 0, PGV_LAB_ATTN_AUX);
-            }
+            if (!(PGV_ATTN_ABL(p) & 4)) dma16(kbase + ((row0 + rr) * p.ld + (slot ^ ((row >> 1) & 7)) * 8) * 2, Ks + g * 1024);
+            if (!(PGV_ATTN_ABL(p) & 1)) dma16(vbase + ((row0 + rr) * p.ld + (slot ^ (((row >> 1) & 1) << 2)) * 8) * 2, Vs + g * 1024);
         }
-    }
-    __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): K / V DMA and the first Q fragments
+    };
+    // Where ONE workgroup owns the CU (336 px: K + V of a head fill its LDS) nobody's compute hides the staging of a unit, so it is cut in two
+    // (round 6): the keys of the first SPLIT chunks are staged and waited for, the rest is requested and lands behind the first chunks of every
+    // wave's FIRST query block, which stops for it once (`tail_pending`).  With two workgroups per CU (224 px) one's staging already runs under
+    // the other's compute: one part.
+    constexpr int SPLIT = PGV_LAB_ATTN_SPLIT;        // chunks of the first part: 288 keys
+    const int g_all = npad / 8;
+    const int g_first = (SPLIT > 0 && NWAVES == 8 && p.nkb > SPLIT * CB) ? SPLIT * CB * 4 : g_all;
+    stage(0, g_first);
+    __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): the (first part of the) K / V DMA and the first Q fragments
     __syncthreads();
+    bool tail_pending = g_first < g_all;             // wave-uniform
+    if (tail_pending) stage(g_first, g_all);
+    auto tail_arrive = [&](int kb0) {                // before the first chunk that reads keys of the second part
+        if (tail_pending && kb0 >= SPLIT * CB) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            __syncthreads();
+            tail_pending = false;
+        }
+    };
 
     const int sw = (lane >> 1) & 7;
     int koffs[4];
@@ -223,9 +246,8 @@ __global__ __launch_bounds__(NWAVES * 64) void vit_attn_kernel(AttnArgs p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) o[j][e] *= alpha;
         }
-        // p = exp2(s * scale - m): one packed FMA per two scores, packed partial sums
+        // p = exp2(s * scale - m): one packed FMA per two scores
         const f32x2_t sc2 = {p.scale_log2e, p.scale_log2e}, nm2 = {-mrun, -mrun};
-        f32x2_t psum2 = {0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < NB; ++c)
 #pragma unroll
@@ -233,8 +255,15 @@ __global__ __launch_bounds__(NWAVES * 64) void vit_attn_kernel(AttnArgs p) {
                 const f32x2_t x = f32x2_t{s[c][e], s[c][e + 1]} * sc2 + nm2;
                 const f32x2_t pv = ((ABL & 8) != 0) ? x : f32x2_t{__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
                 s[c][e] = pv[0]; s[c][e + 1] = pv[1];
-                psum2 += pv;
             }
+        // packed partial row sums in fp32.  (Summing the ROUNDED probabilities two per op with v_dot2c_f32_{f16,bf16} against packed ones -- 24 ops
+        // per chunk where these take 34 -- was built and measured in round 6: 4 % SLOWER at N = 577 (506 against 526 TF/s, same box): the dot
+        // instructions do not issue at the packed-add rate.)
+        f32x2_t psum2 = {0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NB; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) psum2 += f32x2_t{s[c][e], s[c][e + 1]};
         lrun += psum2[0] + psum2[1];
 #pragma unroll
         for (int c = 0; c < NB; ++c)
@@ -270,11 +299,13 @@ __global__ __launch_bounds__(NWAVES * 64) void vit_attn_kernel(AttnArgs p) {
         f32x16_t s[CB];
         int kb0 = 0;
         for (; kb0 + CB < p.nkb; kb0 += CB) {
+            tail_arrive(kb0);
             scores(kb0, qf, s, std::integral_constant<int, CB>{});
             absorb(kb0, s, o, mrun, lrun, std::false_type{}, std::integral_constant<int, CB>{});
         }
         // the last chunk holds 1..CB blocks (wave-uniform) and is the only one that can hold keys >= N
         const int rem = p.nkb - kb0;
+        tail_arrive(kb0);
         if (rem == 1) { scores(kb0, qf, s, std::integral_constant<int, 1>{}); absorb(kb0, s, o, mrun, lrun, std::true_type{}, std::integral_constant<int, 1>{}); }
         else if (rem == 2) { scores(kb0, qf, s, std::integral_constant<int, 2>{}); absorb(kb0, s, o, mrun, lrun, std::true_type{}, std::integral_constant<int, 2>{}); }
         else { scores(kb0, qf, s, std::integral_constant<int, CB>{}); absorb(kb0, s, o, mrun, lrun, std::true_type{}, std::integral_constant<int, CB>{}); }
@@ -305,6 +336,7 @@ __global__ __launch_bounds__(NWAVES * 64) void vit_attn_kernel(AttnArgs p) {
                 for (int m = 0; m < 2; ++m) *(u32x4_t*)(orow + (j * 32 + 16 * m + 8 * hi) * 2) = piece[j][m];
         }
     }
+    tail_arrive(p.nkb);                              // a wave that got no query block still owes the workgroup its barrier (and its DMAs their wait)
 }
 
 }  // namespace

@@ -303,9 +303,18 @@ def answer_tasks(args, tasks, components, load_frames, rank, world):
     import os
     if getattr(args, "batch", "auto") == "auto":
         free_b = torch.cuda.mem_get_info(device)[0] if device.type == "cuda" else 0
-        args.batch = pick_batch(model.config, vision_tower.config.image_size, args.max_new_tokens, free_b) if free_b else 8
+        # processes that share this device see the same free pool and would each claim 70 % of it: PGV_DEVICE_SHARERS (or, in a
+        # shared-device control-flow run, the world size) divides it
+        sharers = int(os.environ.get("PGV_DEVICE_SHARERS", world if os.environ.get("PGV_BENCH_SHARE_DEVICE") else 1))
+        args.batch = pick_batch(model.config, vision_tower.config.image_size, args.max_new_tokens, free_b // max(sharers, 1)) if free_b else 8
+        if world > 1 and torch.distributed.is_available() and torch.distributed.is_initialized():
+            # one group size for the whole job: the smallest any rank can afford (ranks with different free memory would otherwise run
+            # different launch shapes -- same answers, since results do not depend on the batch, but skewed finish times)
+            t = torch.tensor([args.batch], dtype=torch.int32, device=device if torch.distributed.get_backend() == "nccl" else "cpu")
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN)
+            args.batch = int(t[0])
         if rank == 0:
-            print(f"[pgv] --batch auto: {args.batch} clips per group ({free_b / 2 ** 30:.0f} GiB free on {device})", flush=True)
+            print(f"[pgv] --batch auto: {args.batch} clips per group ({free_b / 2 ** 30:.0f} GiB free on {device}, shared by {sharers})", flush=True)
     spill = os.path.join(args.output_dir, args.output_name) if getattr(args, "output_dir", None) and getattr(args, "output_name", None) else None
     if spill:
         os.makedirs(args.output_dir, exist_ok=True)
