@@ -182,8 +182,9 @@ int pgv_llm_prefill(pgv_ctx *ctx, pgv_llm *llm, pgv_kv *kv, const int32_t *h_ids
  * ids carry a placeholder run) -- what a second chat turn is (video_chatgpt/chat.py:108-160 re-tokenises and re-runs the WHOLE conversation
  * every turn although the prefix is unchanged).  Same arguments as pgv_llm_prefill; B must equal the batch of the prefill that filled `kv`;
  * row p of sequence b takes position pgv_kv_len(kv, b) + p, attends to the cached prefix and the new rows before it, and is appended.
- * h_vid_pos is relative to the NEW rows.  Outputs as pgv_llm_prefill (d_all_logits: the new rows only).  An appended row is bitwise the row
- * one full prefill over prefix + new tokens computes. */
+ * h_vid_pos is relative to the NEW rows.  Outputs as pgv_llm_prefill (d_all_logits: the new rows only).  Given the same cache contents an
+ * appended row is bitwise the row of one full prefill over prefix + new tokens (a prefix that pgv_llm_prefill wrote reproduces the one-call
+ * result exactly; entries written by decode steps carry that path's rounding). */
 int pgv_llm_prefill_append(pgv_ctx *ctx, pgv_llm *llm, pgv_kv *kv, const int32_t *h_ids, const int32_t *h_seq_lens, int B,
                            const void *d_video, int V, const int32_t *h_vid_pos, float *d_logits, int32_t *d_next, float *d_all_logits,
                            int ld_all, void *stream);

@@ -486,8 +486,11 @@ def test_13b_bench_call_fp8_bf16_equals_single_clip_runs(ctx):
 # up to 771 + 1023 = 1794 -- decode attention's key loop, RoPE angles and the cache far past the bench's horizon (VERDICT r5 #1b).
 # These run last: they swap the shared vision case to 336 px.
 # ---------------------------------------------------------------------------------------------------------------------------------
-E2E_PIN_336_FP16 = float(os.environ.get("PGV_E2E_PIN", 4.2e-3))     # 1.2 x measured (see LAB.md round 6)
-E2E_PIN_336_BF16 = float(os.environ.get("PGV_E2E_PIN", 4.2e-2))
+# measured on MI355X (gpurun_out/r6s, profiles/r06_s_fulldepth_end_to_end.log): fp16 pooled features 1.84e-4, logits first 1.76e-3 / worst 2.38e-3 over all 1024
+# positions (cache to 1794), 968 / 1024 decisive positions all exact, 255 / 256 free tokens == the oracle's argmax (tail 759 / 768), exact prefix 188; bf16
+# pooled 3.48e-3, logits worst 2.44e-2, 138 / 256 decisive, 243 / 256, prefix 40.  Pins = 1.2 x measured.
+E2E_PIN_336_FP16 = float(os.environ.get("PGV_E2E_PIN", 2.9e-3))
+E2E_PIN_336_BF16 = float(os.environ.get("PGV_E2E_PIN", 3.0e-2))
 
 
 def test_7b_production_336_end_to_end_fp16_256_free_running_then_teacher_forced_to_1024(ctx):

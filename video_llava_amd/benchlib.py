@@ -315,7 +315,9 @@ class Workload:
             out["second_turn"] = {"new_tokens": NEW2, "prompt_tokens": int(o_re.shape[1] - NEW2), "reused_tokens": tm_re.get("reused_tokens"),
                                   "seconds_kv_prefix_kept": t_re, "prefill_s_kv_prefix_kept": tm_re.get("prefill_s"),
                                   "seconds_full_reprefill": t_full, "prefill_s_full_reprefill": tm_full.get("prefill_s"),
-                                  "same_tokens": bool(torch.equal(o_re, o_full))}
+                                  # the kept cache entries of the first answer were written by DECODE steps, the re-prefill recomputes them on the
+                                  # prefill path: same values up to the 16-bit rounding of either path, so a random-init bf16 model can flip a near-tie
+                                  "leading_tokens_equal": int((o_re[0, -NEW2:] != o_full[0, -NEW2:]).int().cumsum(0).eq(0).sum())}
         except Exception as e:                                       # noqa: BLE001 -- a side field
             out["second_turn"] = {"error": f"{type(e).__name__}: {e}"}
         return out

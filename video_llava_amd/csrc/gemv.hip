@@ -674,9 +674,9 @@ __global__ __launch_bounds__(256) void resid_norm_prep_kernel(const float* __res
 
 }  // namespace
 
-// Column tiles of the blocked activation layout for a batch of B sequences (0: row-major -- one MFMA tile of sequences needs no blocking: the
-// merged / masked row loads of the narrow kernels are cheaper there).  The ONE place that decides it: producers and consumers must agree.
-int pgv_gemv_xblk_tiles(int B) { return B <= 16 ? 0 : (B <= 32 ? 2 : 4); }
+// Column tiles of the blocked activation layout for a batch of B sequences (0: row-major -- up to 8 sequences the merged row loads of the
+// narrow kernels, one full line per sequence and group, are cheaper).  The ONE place that decides it: producers and consumers must agree.
+int pgv_gemv_xblk_tiles(int B) { return B <= 8 ? 0 : (B <= 16 ? 1 : (B <= 32 ? 2 : 4)); }
 
 int pgv_launch_final_prep(int dtype, const float* resid, const float* gamma, void* xg, float* ssq, int B, int H, hipStream_t s, bool x_blocked) {
     PGV_CHECK(H % 32 == 0, "final_prep: hidden %d unsupported", H);
@@ -744,7 +744,7 @@ constexpr GemvShape gemv_shape() {
 static const GemvShape kGemvShapes[] = {
     // one MFMA tile of sequences (B <= 16)
     gemv_shape<GV_STORE16, 1, 1>(), gemv_shape<GV_STORE16, 3, 1>(), gemv_shape<GV_STORE16, 4, 1>(), gemv_shape<GV_RESID, 1, 1>(), gemv_shape<GV_SWIGLU, 2, 1>(),
-    gemv_shape<GV_F32, 1, 1>(), gemv_shape<GV_RESIDNORM, 1, 1>(),
+    gemv_shape<GV_F32, 1, 1>(), gemv_shape<GV_F32, 8, 1>(), gemv_shape<GV_RESIDNORM, 1, 1>(),
     // 2 / 4 column tiles (B <= 32 / 64)
     gemv_shape<GV_STORE16, 1, 2>(), gemv_shape<GV_STORE16, 3, 2>(), gemv_shape<GV_RESID, 1, 2>(), gemv_shape<GV_SWIGLU, 2, 2>(), gemv_shape<GV_SWIGLU, 4, 2>(),
     gemv_shape<GV_SWIGLU, 6, 2>(), gemv_shape<GV_F32, 1, 2>(), gemv_shape<GV_F32, 8, 2>(), gemv_shape<GV_RESIDNORM, 1, 2>(),
@@ -830,6 +830,11 @@ static GemvChoice choose_gemv(int mode, bool w8, int B, int grid, int K, int num
                 !(grid % 3 == 0 && grid / 3 == num_cu)) c.tl = 4;
             break;
         case GV_SWIGLU: c.tl = 2; break;
+        case GV_F32:
+            // lm_head at 9 .. 16 sequences: 2001 workgroups of one row block each read the whole activation operand (128 KB against 128 KB of
+            // weights); eight row blocks per workgroup as at the wide batches (251 workgroups, one round)
+            if (!w8 && B > 8 && lab_switch("PGV_GEMV_WIDE_HEAD8", 1) != 0 && (grid + 7) / 8 <= num_cu) c.tl = 8;
+            break;
         case GV_RESIDNORM:
             // fp8 down_proj of the 13B shapes (K = 13 824, 320 row blocks): a 16-row workgroup requests as many activation lines as weight lines
             // (LAB.md "what the activation operand costs"); the 8-phase form reads 1/8 of x per workgroup and is bitwise the same result

@@ -276,7 +276,7 @@ extern "C" int pgv_kv_create(pgv_ctx* ctx, pgv_llm* llm, int batch, int max_seq,
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += pgv_align(bytes); return o; };
     const size_t o_cache = take(per * 2 * L);
-    const size_t o_resid = take(B * H * 4), o_xn = take(CTn * 16 * H * 2),      // xn: row-major [B][H] up to 16 sequences, fragment-blocked [H / 32][CTn][4][16][8] beyond (gv_xblk_offset)
+    const size_t o_resid = take(B * H * 4), o_xn = take(CTn * 16 * H * 2),      // xn: row-major [B][H] up to 8 sequences, fragment-blocked [H / 32][CTn][4][16][8] beyond (gv_xblk_offset)
                  o_qkv = take(B * 3 * H * 2), o_ao = take(B * H * 2), o_act = take(B * I * 2),
                  o_logits = take(B * V * 4), o_ssq = take(CTn * H * 4), o_av = take(CTn * V * 4), o_ai = take(CTn * V * 4), o_ints = take((4 * B + B * (size_t)max_seq) * 4),
                  o_u = take(B * (size_t)max_seq * 4), o_dpart = take(B * llm->cfg.heads * (size_t)kDattnSplitMax * kDattnPart * 4), o_dtick = take(B * llm->cfg.heads * 4),

@@ -120,6 +120,12 @@ __global__ __launch_bounds__(NWAVES * 64) void vit_attn_kernel(AttnArgs p) {
     // do not read it).  With __builtin_amdgcn_global_load_lds hipcc puts s_waitcnt vmcnt(0) in front of the V fragment reads of EVERY chunk while
     // a DMA may be pending (it cannot tell the rows a pending DMA writes from the rows a chunk reads), which would end the overlap below at the
     // first chunk and drain the Q prefetch and the output stores in every later one.  The waits that order DMA and reads are explicit.
+#ifndef PGV_LAB_ATTN_PRIO
+#define PGV_LAB_ATTN_PRIO 0            // lab A/B: 1 = s_setprio(1) around the MFMA clusters, 2 = static priority for the younger half of the waves
+#endif
+#ifndef PGV_LAB_ATTN_STAGGER
+#define PGV_LAB_ATTN_STAGGER 0         // lab A/B: s_sleep N (x 64 cycles) for the upper half of the waves before the query loop: de-phases the two waves of a SIMD
+#endif
 #ifndef PGV_LAB_ATTN_SPLIT
 #define PGV_LAB_ATTN_SPLIT 3           // lab A/B: chunks of the first staging part where one workgroup owns the CU; 0 = one part
 #endif
@@ -188,6 +194,7 @@ __global__ __launch_bounds__(NWAVES * 64) void vit_attn_kernel(AttnArgs p) {
         for (int c = 0; c < NB; ++c)
 #pragma unroll
             for (int e = 0; e < 16; ++e) s[c][e] = 0.f;
+        if constexpr ((PGV_LAB_ATTN_PRIO & 1) != 0) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -195,6 +202,7 @@ __global__ __launch_bounds__(NWAVES * 64) void vit_attn_kernel(AttnArgs p) {
                 if constexpr ((ABL & 32) != 0) { s[c][kk] += (float)kf[c][kk][0] * (float)qf[kk][0]; continue; }
                 s[c] = T::mfma32(kf[c][kk], qf[kk], s[c]);
             }
+        if constexpr ((PGV_LAB_ATTN_PRIO & 1) != 0) __builtin_amdgcn_s_setprio(0);
     };
     // Online-softmax update with one chunk of scores and O^T += V^T . P^T.  MASK: the chunk may hold keys >= N.
     auto absorb = [&](int kb0, f32x16_t (&s)[CB], f32x16_t (&o)[2], float& mrun, float& lrun, auto mask_tag, auto nb_tag) __attribute__((always_inline)) {
@@ -280,6 +288,8 @@ __global__ __launch_bounds__(NWAVES * 64) void vit_attn_kernel(AttnArgs p) {
             }
     };
 
+    if constexpr ((PGV_LAB_ATTN_PRIO & 2) != 0) { if (w >= NWAVES / 2) __builtin_amdgcn_s_setprio(1); }
+    if constexpr (PGV_LAB_ATTN_STAGGER > 0) { if (w >= NWAVES / 2) __builtin_amdgcn_s_sleep(PGV_LAB_ATTN_STAGGER); }
     const int nblocks = (PGV_ATTN_ABL(p) & 2) ? 0 : p.nkb;
     int qb = w, qb_next = next_block();
     for (; qb < nblocks; qb = qb_next, qb_next = next_block()) {

@@ -509,8 +509,10 @@ class VideoChatGPTLlamaForCausalLM(nn.Module):
         `kv_reuse_key` (B == 1; any hashable naming the conversation's video, None = off): keep the KV cache of this call for the next one with
         the same key -- a later chat turn whose prompt extends what the cache holds prefills only the NEW tokens behind the common prefix
         (pgv_kv_truncate + pgv_llm_prefill_append; the reference re-runs the whole conversation every turn, chat.py:108-160).  The video run
-        must lie inside the common prefix (it was spliced when the cache was filled); otherwise the call falls back to a full prefill.  Token-
-        and logits-identical to the full prefill (appended rows are bitwise the rows of one pass).  `timings["reused_tokens"]` reports the prefix."""
+        must lie inside the common prefix (it was spliced when the cache was filled); otherwise the call falls back to a full prefill.  The
+        appended rows are bitwise what one prefill over the same cache contents computes; cache entries that DECODE steps wrote (the previous
+        answer) carry the decode path's 16-bit rounding instead of the prefill path's -- as with any KV cache that is kept across calls.
+        `timings["reused_tokens"]` reports the prefix."""
         if torch.is_tensor(input_ids):
             seqs = [row.tolist() for row in input_ids.cpu()]
         else:
