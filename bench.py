@@ -561,7 +561,9 @@ def main():
                                           # the PRODUCTION configuration of the released PG-Video-LLaVA weights (reference docs/1-CLI_DEMO.md:27-44): ViT-L/14-336
                                           # (577 tokens per frame), mlp2x_gelu projector, 676 video tokens -- with its own rooflines
                                           ("image336", {"image": 336}, 3, 1, True),
-                                          ("clips32", {"clips_per_gpu": 32}, 1, 1, False)):     # what a long runner queue would use: the weight stream of a token step shared by 32 clips
+                                          ("clips32", {"clips_per_gpu": 32}, 1, 1, False),      # what a long runner queue would use: the weight stream of a token step shared by 32 clips
+                                          # ... and by 64: what `--batch auto` picks on an MI355X next to a 7B replica, with the wide-batch GEMV roofline
+                                          ("clips64", {"clips_per_gpu": 64}, 1, 1, True)):
                 try:
                     side[key] = side_line(args, dev, ov, st, wu, roof)
                 except Exception as e:                           # noqa: BLE001

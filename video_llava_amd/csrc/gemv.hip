@@ -74,7 +74,7 @@ __device__ __forceinline__ typename T::v8 fp8x8_to_v8(unsigned lo, unsigned hi) 
     return r;
 }
 
-// NW = waves per workgroup (the K split inside a workgroup): 8.  The residual producers cannot split K across workgroups (the workgroup that
+// NW = kGemvWaves = waves per workgroup (the K split inside a workgroup): 8.  The residual producers cannot split K across workgroups (the workgroup that
 // owns 16 output rows must see their complete sums to emit xg and the sum of squares), so o_proj / down_proj run 256 workgroups = one per CU
 // with 8 waves; the pipelined weight stream below keeps enough loads in flight for that (down_proj 16.4 us; a 16-wave variant, needed
 // before the stream was pipelined, takes 19.3 us: twice the LDS partials and 12 % dead tail loads at 10.75 groups per wave).
@@ -96,8 +96,15 @@ __device__ __forceinline__ typename T::v8 fp8x8_to_v8(unsigned lo, unsigned hi) 
 // (An fp8 x fp8 MFMA form -- e4m3 weight codes straight into v_mfma_f32_16x16x32_fp8_fp8 against a hi + lo e4m3 image of the activations -- was
 // built and measured in round 4: slower (one more launch per GEMV) and 2.6 x less accurate than this weight-only form; removed in round 5,
 // the study is in LAB.md.)
-template <typename T, int MODE, bool W8, int NW, int TL, int PU, bool X2, int CT = 1>
-__global__ __launch_bounds__(NW * 64) void gemv_mfma_kernel(GemvArgs p) {
+// register-buffer depth (64-column groups per buffer): one row block per workgroup buffers 2 groups, 2 - 3 row blocks 1; an fp8 group is one 16-byte
+// load per lane and row block where a 16-bit group is two, so the fp8 variants buffer twice as many groups for the same bytes in flight; batches
+// beyond one MFMA tile keep one group per buffer (the x fragments of CT tiles fill the registers)
+constexpr int gemv_pu(int tl, bool w8, int ct) { return (ct > 1 || tl >= 6) ? 1 : (tl == 1 ? 2 : 1) * (w8 ? 2 : 1); }
+constexpr int kGemvWaves = 8;          // waves per workgroup = K phases of a row block (the arithmetic of every launch shape is defined on these 8 chains)
+
+template <typename T, int MODE, bool W8, int TL, bool X2, int CT = 1>
+__global__ __launch_bounds__(kGemvWaves * 64) void gemv_mfma_kernel(GemvArgs p) {
+    constexpr int NW = kGemvWaves, PU = gemv_pu(TL, W8, CT);
     constexpr int TILES = TL;
     static_assert(!X2 || CT == 1, "the merged x load uses the lanes of columns 8..15");
     // HS (six row blocks and more): the weight stream is pipelined in HALF groups (one 32-column k-block per register buffer) -- a whole group of
@@ -712,20 +719,15 @@ static int lab_switch(const char* name, int dflt) {
 
 using gemv_launch_fn = int (*)(int dtype, int grid, const GemvArgs& a, hipStream_t s);
 
-template <int MODE, bool W8, int TL, int PU, bool X2, int CT>
+template <int MODE, bool W8, int TL, bool X2, int CT>
 static int launch_variant(int dtype, int grid, const GemvArgs& a, hipStream_t s) {
-    PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gemv_mfma_kernel<T, MODE, W8, 8, TL, PU, X2, CT>), dim3(grid), dim3(512), 0, s, a));
+    PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gemv_mfma_kernel<T, MODE, W8, TL, X2, CT>), dim3(grid), dim3(kGemvWaves * 64), 0, s, a));
     return PGV_OK;
 }
 
-// register-buffer depth (64-column groups per buffer): one row block per workgroup buffers 2 groups, 2 - 3 row blocks 1; an fp8 group is one 16-byte
-// load per lane and row block where a 16-bit group is two, so the fp8 variants buffer twice as many groups for the same bytes in flight; batches
-// beyond one MFMA tile keep one group per buffer (the x fragments of CT tiles fill the registers)
-constexpr int gemv_pu(int tl, bool w8, int ct) { return ct > 1 ? 1 : (tl == 1 ? 2 : 1) * (w8 ? 2 : 1); }
-
 template <int MODE, bool W8, int TL, int CT>
-constexpr gemv_launch_fn x2_variant() {          // the merged x load (B <= 8) uses the lanes of batch columns 8..15: one column tile only
-    if constexpr (CT == 1) return &launch_variant<MODE, W8, TL, gemv_pu(TL, W8, 1), true, 1>;
+constexpr gemv_launch_fn x2_variant() {          // the merged x load (B <= 8) uses the lanes of batch columns 8..15: one column tile only, not the half-group pipeline
+    if constexpr (CT == 1 && TL < 6) return &launch_variant<MODE, W8, TL, true, 1>;
     else return nullptr;
 }
 
@@ -735,11 +737,11 @@ struct GemvShape {
 };
 template <int MODE, int TL, int CT>
 constexpr GemvShape gemv_shape() {
-    if constexpr (TL >= 6)                       // half-group pipelining: 16-bit weights only (an fp8 group is ONE load per lane), wide batches only
-        return {MODE, TL, CT, {{&launch_variant<MODE, false, TL, 1, false, CT>, nullptr}, {nullptr, nullptr}}};
+    if constexpr (TL >= 6)                       // half-group pipelining: 16-bit weights only (an fp8 group is ONE load per lane)
+        return {MODE, TL, CT, {{&launch_variant<MODE, false, TL, false, CT>, nullptr}, {nullptr, nullptr}}};
     else
-        return {MODE, TL, CT, {{&launch_variant<MODE, false, TL, gemv_pu(TL, false, CT), false, CT>, x2_variant<MODE, false, TL, CT>()},
-                               {&launch_variant<MODE, true, TL, gemv_pu(TL, true, CT), false, CT>, x2_variant<MODE, true, TL, CT>()}}};
+        return {MODE, TL, CT, {{&launch_variant<MODE, false, TL, false, CT>, x2_variant<MODE, false, TL, CT>()},
+                               {&launch_variant<MODE, true, TL, false, CT>, x2_variant<MODE, true, TL, CT>()}}};
 }
 static const GemvShape kGemvShapes[] = {
     // one MFMA tile of sequences (B <= 16)

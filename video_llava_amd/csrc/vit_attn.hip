@@ -205,9 +205,20 @@ __global__ __launch_bounds__(NWAVES * 64) void vit_attn_kernel(AttnArgs p) {
         if constexpr ((PGV_LAB_ATTN_PRIO & 1) != 0) __builtin_amdgcn_s_setprio(0);
     };
     // Online-softmax update with one chunk of scores and O^T += V^T . P^T.  MASK: the chunk may hold keys >= N.
-    auto absorb = [&](int kb0, f32x16_t (&s)[CB], f32x16_t (&o)[2], float& mrun, float& lrun, auto mask_tag, auto nb_tag) __attribute__((always_inline)) {
+    // SPEC (round 6): every chunk but a query block's first is absorbed SPECULATIVELY -- no chunk maximum, no rescale: p = exp2(s * scale - m) with
+    // the running m as it stands.  The row sums that are computed anyway tell whether that was legitimate: all p >= 0, so a lane's partial sum
+    // bounds each of its p, and `sum <= SPEC_LIMIT` guarantees p <= 2^12 (exact in fp32, representable in fp16 / bf16, same relative rounding as
+    // any other p).  The wave-uniform test replaces the 24 v_max3 + 6 v_max + cross-half swap per chunk; when it fails (a score more than 2^12
+    // above the running maximum of the chunks before: after a block's first chunk practically never) the lambda returns false with nothing
+    // accumulated and the caller recomputes the scores and takes the exact path.  Mathematically the same softmax either way.
+#ifndef PGV_LAB_ATTN_SPEC
+#define PGV_LAB_ATTN_SPEC 1            // lab A/B: 0 = chunk maximum + lazy rescale on every chunk (round 5)
+#endif
+    constexpr float SPEC_LIMIT = 4096.0f;
+    auto absorb = [&](int kb0, f32x16_t (&s)[CB], f32x16_t (&o)[2], float& mrun, float& lrun, auto mask_tag, auto nb_tag, auto spec_tag) __attribute__((always_inline)) -> bool {
         constexpr bool MASK = decltype(mask_tag)::value;
         constexpr int NB = decltype(nb_tag)::value;
+        constexpr bool SPEC = decltype(spec_tag)::value;
         // V^T fragments of the chunk: issued first, their LDS latency hides under the softmax arithmetic
         typename T::v8 vf[NB][2][2];
 #pragma unroll
@@ -234,6 +245,7 @@ __global__ __launch_bounds__(NWAVES * 64) void vit_attn_kernel(AttnArgs p) {
                 }
             }
         }
+      if constexpr (!SPEC) {
         float cmax = NEG;
         if constexpr ((ABL & 64) != 0) cmax = s[0][0];
         else {
@@ -254,6 +266,7 @@ __global__ __launch_bounds__(NWAVES * 64) void vit_attn_kernel(AttnArgs p) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) o[j][e] *= alpha;
         }
+      }
         // p = exp2(s * scale - m): one packed FMA per two scores
         const f32x2_t sc2 = {p.scale_log2e, p.scale_log2e}, nm2 = {-mrun, -mrun};
 #pragma unroll
@@ -272,7 +285,11 @@ __global__ __launch_bounds__(NWAVES * 64) void vit_attn_kernel(AttnArgs p) {
         for (int c = 0; c < NB; ++c)
 #pragma unroll
             for (int e = 0; e < 16; e += 2) psum2 += f32x2_t{s[c][e], s[c][e + 1]};
-        lrun += psum2[0] + psum2[1];
+        const float psum = psum2[0] + psum2[1];
+        if constexpr (SPEC) {
+            if (__builtin_amdgcn_ballot_w64(!(psum <= SPEC_LIMIT)) != 0ull) return false;      // wave-uniform; NaN / inf fail too
+        }
+        lrun += psum;
 #pragma unroll
         for (int c = 0; c < NB; ++c)
 #pragma unroll
@@ -286,6 +303,16 @@ __global__ __launch_bounds__(NWAVES * 64) void vit_attn_kernel(AttnArgs p) {
                     o[j] = T::mfma32(vf[c][ks][j], pa, o[j]);
                 }
             }
+        return true;
+    };
+    // one chunk: scores, then the speculative absorb (not on a block's first chunk: m is still NEG there), the exact one if that declines
+    auto chunk = [&](int kb0, const typename T::v8 (&qf)[4], f32x16_t (&s)[CB], f32x16_t (&o)[2], float& mrun, float& lrun, auto mask_tag, auto nb_tag) __attribute__((always_inline)) {
+        scores(kb0, qf, s, nb_tag);
+        if (PGV_LAB_ATTN_SPEC && kb0 > 0) {
+            if (absorb(kb0, s, o, mrun, lrun, mask_tag, nb_tag, std::true_type{})) return;
+            scores(kb0, qf, s, nb_tag);              // the probabilities overwrote the scores
+        }
+        absorb(kb0, s, o, mrun, lrun, mask_tag, nb_tag, std::false_type{});
     };
 
     if constexpr ((PGV_LAB_ATTN_PRIO & 2) != 0) { if (w >= NWAVES / 2) __builtin_amdgcn_s_setprio(1); }
@@ -310,15 +337,14 @@ __global__ __launch_bounds__(NWAVES * 64) void vit_attn_kernel(AttnArgs p) {
         int kb0 = 0;
         for (; kb0 + CB < p.nkb; kb0 += CB) {
             tail_arrive(kb0);
-            scores(kb0, qf, s, std::integral_constant<int, CB>{});
-            absorb(kb0, s, o, mrun, lrun, std::false_type{}, std::integral_constant<int, CB>{});
+            chunk(kb0, qf, s, o, mrun, lrun, std::false_type{}, std::integral_constant<int, CB>{});
         }
         // the last chunk holds 1..CB blocks (wave-uniform) and is the only one that can hold keys >= N
         const int rem = p.nkb - kb0;
         tail_arrive(kb0);
-        if (rem == 1) { scores(kb0, qf, s, std::integral_constant<int, 1>{}); absorb(kb0, s, o, mrun, lrun, std::true_type{}, std::integral_constant<int, 1>{}); }
-        else if (rem == 2) { scores(kb0, qf, s, std::integral_constant<int, 2>{}); absorb(kb0, s, o, mrun, lrun, std::true_type{}, std::integral_constant<int, 2>{}); }
-        else { scores(kb0, qf, s, std::integral_constant<int, CB>{}); absorb(kb0, s, o, mrun, lrun, std::true_type{}, std::integral_constant<int, CB>{}); }
+        if (rem == 1) chunk(kb0, qf, s, o, mrun, lrun, std::true_type{}, std::integral_constant<int, 1>{});
+        else if (rem == 2) chunk(kb0, qf, s, o, mrun, lrun, std::true_type{}, std::integral_constant<int, 2>{});
+        else chunk(kb0, qf, s, o, mrun, lrun, std::true_type{}, std::integral_constant<int, CB>{});
 
         __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0): the next block's Q (requested a whole block ago); see load_q
         const float ltot = half_swap_sum(lrun);
