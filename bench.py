@@ -43,7 +43,7 @@ sys.path.insert(0, ROOT)
 # the CPU-baseline child is placed from the original mask (one hardware thread per physical core of one node), not from the rank's slice.
 ORIG_AFFINITY = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
 
-from video_llava_amd.benchlib import PEAK_MFMA_TFLOPS, Workload, dry_pattern, runner_measurement, side_line, time_collective  # noqa: E402
+from video_llava_amd.benchlib import PEAK_MFMA_TFLOPS, Workload, dry_pattern, make_prompts, runner_measurement, side_line, time_collective  # noqa: E402
 
 
 def parse():

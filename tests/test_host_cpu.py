@@ -391,6 +391,32 @@ def test_collective_identity_refuses_shared_devices_and_parses_the_rccl_log(tmp_
     assert parallel.rccl_transport(cleanup=False)["verdict"] == "SHM"
 
 
+@pytest.mark.parametrize("rel", ["bench.py", "video_llava_amd/benchlib.py", "__graft_entry__.py"])
+def test_measurement_scripts_have_no_undefined_names(rel):
+    """bench.py's CPU-baseline child only runs at the end of a GPU bench (it builds a 27 GB fp32 model), so a name that went missing in a refactor
+    -- `make_prompts` after the measurement library was split out of the script, round 6 -- shows up as `cpu_baseline.value = null` on the
+    driver's box and nowhere else.  Every name a function of these files loads must be defined in the file, imported, or a builtin."""
+    import ast
+    import builtins
+    tree = ast.parse(open(os.path.join(ROOT, rel)).read())
+    defined = set(dir(builtins)) | {"__file__", "__name__"}
+    for n in ast.walk(tree):
+        if isinstance(n, (ast.FunctionDef, ast.ClassDef)):
+            defined.add(n.name)
+        elif isinstance(n, ast.Import):
+            defined.update((a.asname or a.name).split(".")[0] for a in n.names)
+        elif isinstance(n, ast.ImportFrom):
+            defined.update(a.asname or a.name for a in n.names)
+        elif isinstance(n, ast.Name) and isinstance(n.ctx, (ast.Store, ast.Del)):
+            defined.add(n.id)
+        elif isinstance(n, ast.arg):
+            defined.add(n.arg)
+        elif isinstance(n, ast.ExceptHandler) and n.name:
+            defined.add(n.name)
+    used = {n.id for n in ast.walk(tree) if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load)}
+    assert not (used - defined), sorted(used - defined)
+
+
 def test_bench_gpus_mismatch_is_loud():
     """A WORLD_SIZE that contradicts --gpus is an error, not a silently different run."""
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")

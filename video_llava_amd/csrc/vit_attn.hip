@@ -204,90 +204,102 @@ __global__ __launch_bounds__(NWAVES * 64) void vit_attn_kernel(AttnArgs p) {
             }
         if constexpr ((PGV_LAB_ATTN_PRIO & 1) != 0) __builtin_amdgcn_s_setprio(0);
     };
-    // Online-softmax update with one chunk of scores and O^T += V^T . P^T.  MASK: the chunk may hold keys >= N.
-    // SPEC (round 6): every chunk but a query block's first is absorbed SPECULATIVELY -- no chunk maximum, no rescale: p = exp2(s * scale - m) with
-    // the running m as it stands.  The row sums that are computed anyway tell whether that was legitimate: all p >= 0, so a lane's partial sum
-    // bounds each of its p, and `sum <= SPEC_LIMIT` guarantees p <= 2^12 (exact in fp32, representable in fp16 / bf16, same relative rounding as
-    // any other p).  The wave-uniform test replaces the 24 v_max3 + 6 v_max + cross-half swap per chunk; when it fails (a score more than 2^12
-    // above the running maximum of the chunks before: after a block's first chunk practically never) the lambda returns false with nothing
-    // accumulated and the caller recomputes the scores and takes the exact path.  Mathematically the same softmax either way.
+    // One chunk of keys: scores, online-softmax update, O^T += V^T . P^T.  MASK: the chunk may hold keys >= N.
+    // Every chunk but a query block's first is absorbed SPECULATIVELY (round 6) -- no chunk maximum, no rescale: p = exp2(s * scale - m) with the
+    // running m as it stands.  The row sums that are computed anyway tell whether that was legitimate: all p >= 0, so a lane's partial sum bounds
+    // each of its p, and `sum <= SPEC_LIMIT` guarantees p <= 2^12 (exact in fp32, representable in fp16 / bf16, same relative rounding as any
+    // other p).  The wave-uniform test replaces the 24 v_max3 + 6 v_max + cross-half swap of a chunk; when it fails (a score more than 2^12 above the
+    // running maximum of the chunks before: after a block's first chunk practically never) nothing has been accumulated yet: the scores are
+    // recomputed and the chunk takes the exact path (maximum, lazy rescale).  Mathematically the same softmax either way.
 #ifndef PGV_LAB_ATTN_SPEC
 #define PGV_LAB_ATTN_SPEC 1            // lab A/B: 0 = chunk maximum + lazy rescale on every chunk (round 5)
 #endif
     constexpr float SPEC_LIMIT = 4096.0f;
-    auto absorb = [&](int kb0, f32x16_t (&s)[CB], f32x16_t (&o)[2], float& mrun, float& lrun, auto mask_tag, auto nb_tag, auto spec_tag) __attribute__((always_inline)) -> bool {
+    auto chunk = [&](int kb0, const typename T::v8 (&qf)[4], f32x16_t (&s)[CB], f32x16_t (&o)[2], float& mrun, float& lrun, auto mask_tag, auto nb_tag) __attribute__((always_inline)) {
         constexpr bool MASK = decltype(mask_tag)::value;
         constexpr int NB = decltype(nb_tag)::value;
-        constexpr bool SPEC = decltype(spec_tag)::value;
-        // V^T fragments of the chunk: issued first, their LDS latency hides under the softmax arithmetic
         typename T::v8 vf[NB][2][2];
+        // V^T fragments of the chunk: issued first, their LDS latency hides under the softmax arithmetic
+        auto load_v = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int c = 0; c < NB; ++c) {
-            const char* vb = Vs + (size_t)(kb0 + c) * 4096;
+            for (int c = 0; c < NB; ++c) {
+                const char* vb = Vs + (size_t)(kb0 + c) * 4096;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+                for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const char* a0 = vb + (voff0 ^ (j * 64)) + ks * 2048;
-                    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)a0);
-                    const s16x4_t up = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(a0 + 1024));
-                    vf[c][ks][j] = __builtin_bit_cast(typename T::v8, __builtin_shufflevector(lo, up, 0, 1, 2, 3, 4, 5, 6, 7));
-                }
-        }
-        if constexpr (MASK) {
-            constexpr int c = NB - 1;                            // only the last existing block can hold keys >= N
-            if ((kb0 + c + 1) * 32 > N) {                        // wave-uniform
-                const int kbase_idx = (kb0 + c) * 32 + 4 * hi;
+                    for (int j = 0; j < 2; ++j) {
+                        const char* a0 = vb + (voff0 ^ (j * 64)) + ks * 2048;
+                        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)a0);
+                        const s16x4_t up = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(a0 + 1024));
+                        vf[c][ks][j] = __builtin_bit_cast(typename T::v8, __builtin_shufflevector(lo, up, 0, 1, 2, 3, 4, 5, 6, 7));
+                    }
+            }
+        };
+        auto mask = [&]() __attribute__((always_inline)) {
+            if constexpr (MASK) {
+                constexpr int c = NB - 1;                            // only the last existing block can hold keys >= N
+                if ((kb0 + c + 1) * 32 > N) {                        // wave-uniform
+                    const int kbase_idx = (kb0 + c) * 32 + 4 * hi;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int key = kbase_idx + (e & 3) + 8 * (e >> 2);
-                    s[c][e] = (key < N) ? s[c][e] : NEG;
+                    for (int e = 0; e < 16; ++e) {
+                        const int key = kbase_idx + (e & 3) + 8 * (e >> 2);
+                        s[c][e] = (key < N) ? s[c][e] : NEG;
+                    }
                 }
             }
-        }
-      if constexpr (!SPEC) {
-        float cmax = NEG;
-        if constexpr ((ABL & 64) != 0) cmax = s[0][0];
-        else {
+        };
+        // p = exp2(s * scale - m) over the chunk (one packed FMA per two scores), in place; returns the lane's partial row sum
+        auto probs = [&](float m) __attribute__((always_inline)) -> float {
+            const f32x2_t sc2 = {p.scale_log2e, p.scale_log2e}, nm2 = {-m, -m};
+            f32x2_t psum2 = {0.f, 0.f};
 #pragma unroll
             for (int c = 0; c < NB; ++c)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) cmax = fmaxf(cmax, s[c][e]);
-            cmax = half_swap_max(cmax);
-        }
-        const float cm = cmax * p.scale_log2e;
-        if (__builtin_amdgcn_ballot_w64(cm > mrun + PGV_LAB_ATTN_LAZY_TH) != 0ull) {      // wave-uniform; always taken on a block's first chunk (mrun = NEG)
-            const float mnew = fmaxf(mrun, cm);
-            const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
-            mrun = mnew;
-            lrun *= alpha;
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) o[j][e] *= alpha;
-        }
-      }
-        // p = exp2(s * scale - m): one packed FMA per two scores
-        const f32x2_t sc2 = {p.scale_log2e, p.scale_log2e}, nm2 = {-mrun, -mrun};
-#pragma unroll
-        for (int c = 0; c < NB; ++c)
-#pragma unroll
-            for (int e = 0; e < 16; e += 2) {
-                const f32x2_t x = f32x2_t{s[c][e], s[c][e + 1]} * sc2 + nm2;
-                const f32x2_t pv = ((ABL & 8) != 0) ? x : f32x2_t{__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
-                s[c][e] = pv[0]; s[c][e + 1] = pv[1];
+                for (int e = 0; e < 16; e += 2) {
+                    const f32x2_t x = f32x2_t{s[c][e], s[c][e + 1]} * sc2 + nm2;
+                    const f32x2_t pv = ((ABL & 8) != 0) ? x : f32x2_t{__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+                    s[c][e] = pv[0]; s[c][e + 1] = pv[1];
+                    psum2 += pv;
+                }
+            return psum2[0] + psum2[1];
+        };
+        scores(kb0, qf, s, nb_tag);
+        load_v();
+        mask();
+        bool exact = !(PGV_LAB_ATTN_SPEC && kb0 > 0);                // wave-uniform
+        float psum = 0.f;
+        if (!exact) {
+            psum = probs(mrun);
+            if (__builtin_amdgcn_ballot_w64(!(psum <= SPEC_LIMIT)) != 0ull) {      // NaN / inf fail too
+                exact = true;                                        // nothing accumulated yet: start the chunk over
+                scores(kb0, qf, s, nb_tag);
+                load_v();
+                mask();
             }
-        // packed partial row sums in fp32.  (Summing the ROUNDED probabilities two per op with v_dot2c_f32_{f16,bf16} against packed ones -- 24 ops
-        // per chunk where these take 34 -- was built and measured in round 6: 4 % SLOWER at N = 577 (506 against 526 TF/s, same box): the dot
-        // instructions do not issue at the packed-add rate.)
-        f32x2_t psum2 = {0.f, 0.f};
+        }
+        if (exact) {
+            float cmax = NEG;
+            if constexpr ((ABL & 64) != 0) cmax = s[0][0];
+            else {
 #pragma unroll
-        for (int c = 0; c < NB; ++c)
+                for (int c = 0; c < NB; ++c)
 #pragma unroll
-            for (int e = 0; e < 16; e += 2) psum2 += f32x2_t{s[c][e], s[c][e + 1]};
-        const float psum = psum2[0] + psum2[1];
-        if constexpr (SPEC) {
-            if (__builtin_amdgcn_ballot_w64(!(psum <= SPEC_LIMIT)) != 0ull) return false;      // wave-uniform; NaN / inf fail too
+                    for (int e = 0; e < 16; ++e) cmax = fmaxf(cmax, s[c][e]);
+                cmax = half_swap_max(cmax);
+            }
+            const float cm = cmax * p.scale_log2e;
+            // Lazy rescale (round 5, see PGV_LAB_ATTN_LAZY_TH): only when some query of the wave saw a score more than LAZY_TH above its running maximum
+            if (__builtin_amdgcn_ballot_w64(cm > mrun + PGV_LAB_ATTN_LAZY_TH) != 0ull) {      // wave-uniform; always taken on a block's first chunk (mrun = NEG)
+                const float mnew = fmaxf(mrun, cm);
+                const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+                mrun = mnew;
+                lrun *= alpha;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) o[j][e] *= alpha;
+            }
+            psum = probs(mrun);
         }
         lrun += psum;
 #pragma unroll
@@ -303,16 +315,6 @@ __global__ __launch_bounds__(NWAVES * 64) void vit_attn_kernel(AttnArgs p) {
                     o[j] = T::mfma32(vf[c][ks][j], pa, o[j]);
                 }
             }
-        return true;
-    };
-    // one chunk: scores, then the speculative absorb (not on a block's first chunk: m is still NEG there), the exact one if that declines
-    auto chunk = [&](int kb0, const typename T::v8 (&qf)[4], f32x16_t (&s)[CB], f32x16_t (&o)[2], float& mrun, float& lrun, auto mask_tag, auto nb_tag) __attribute__((always_inline)) {
-        scores(kb0, qf, s, nb_tag);
-        if (PGV_LAB_ATTN_SPEC && kb0 > 0) {
-            if (absorb(kb0, s, o, mrun, lrun, mask_tag, nb_tag, std::true_type{})) return;
-            scores(kb0, qf, s, nb_tag);              // the probabilities overwrote the scores
-        }
-        absorb(kb0, s, o, mrun, lrun, mask_tag, nb_tag, std::false_type{});
     };
 
     if constexpr ((PGV_LAB_ATTN_PRIO & 2) != 0) { if (w >= NWAVES / 2) __builtin_amdgcn_s_setprio(1); }
