@@ -549,6 +549,8 @@ def main():
             line["roofline"] = roofline
             if getattr(wl, "roofline_mfma", None):
                 line["roofline_mfma"] = wl.roofline_mfma
+            if getattr(wl, "roofline_gemv", None):
+                line["roofline_gemv"] = wl.roofline_gemv
         headline = (args.workload == "full" and args.llm == "7b" and args.weights == "16bit" and args.dtype == "bf16" and S == 224 and world == 1)
         if headline and not args.no_side:
             # Guarded side lines: driver-timed numbers for the parity-grade dtype and for BASELINE configs[4]; a failure costs

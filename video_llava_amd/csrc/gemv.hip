@@ -532,7 +532,7 @@ __global__ __launch_bounds__(NWB * 64) void gemv_k8_kernel(GemvArgs p, f32x4_t* 
     f32x4_t acc[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) acc[ct] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    constexpr int PU = 4;                                        // groups per register buffer
+    constexpr int PU = 4;                                        // groups per register buffer (3 / 4 / 6 at 64 sequences: 14.7 / 15.3 / 15.5 us per launch, gpurun_out/r6n: not the lever)
     auto wload = [&](wreg_t (&wf)[PU][WH], int gi0) {
 #pragma unroll
         for (int u = 0; u < PU; ++u) {
