@@ -391,7 +391,12 @@ def test_kv_bounds_and_errors(ctx):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float16, 1e-3), (torch.bfloat16, 8e-3)])
-@pytest.mark.parametrize("mode,N,K,B", [(0, 1536, 512, 3), (1, 512, 768, 8), (2, 1536, 512, 16), (3, 515, 512, 5), (0, 12288, 4096, 8)])
+@pytest.mark.parametrize("mode,N,K,B", [(0, 1536, 512, 3), (1, 512, 768, 8), (2, 1536, 512, 16), (3, 515, 512, 5), (0, 12288, 4096, 8),
+                                        # the wide-batch launch shapes of round 6 against fp32 directly (not only through batch invariance): gate/up with
+                                        # three (gate, up) pairs per workgroup (688 pairs: a ragged last workgroup), lm_head with eight row blocks
+                                        # (2001 row blocks: seven tiles past the matrix in the last workgroup), at two and four column tiles
+                                        (2, 22016, 4096, 64), (2, 22016, 4096, 19), (3, 32003, 4096, 40), (3, 32003, 4096, 12), (0, 12288, 4096, 64),
+                                        (1, 4096, 4096, 33)])
 def test_gemv_building_block(ctx, dtype, tol, mode, N, K, B):
     """pgv_gemv on fragment-blocked weights (pgv_pack_blocked) vs torch fp32, every epilogue mode."""
     from video_llava_amd import _lib
