@@ -250,15 +250,25 @@ def answer_tasks(args, tasks, components, load_frames, rank, world):
                 for r, j in enumerate(keep):
                     record(j, out[r], len(prompts[r]))
             except Exception as e:                                     # noqa: BLE001
-                # one bad sample (e.g. an over-long prompt) must not take the whole group down: the reference loses only that sample
-                print(f"batched generation failed ({e}); retrying the {len(keep)} samples one by one")
-                for r, j in enumerate(keep):
+                # one bad sample (e.g. an over-long prompt) must not take the whole group down: the reference loses only that sample.  Out of
+                # memory (the KV cache of the group did not fit next to whatever else lives on the device: ADVICE r5) is not a sample's fault:
+                # halve the group until it fits, one by one only for everything else
+                oom = isinstance(e, (MemoryError, torch.cuda.OutOfMemoryError))
+                size = max(1, len(keep) // 2) if oom and len(keep) > 1 else 1
+                print(f"batched generation failed ({type(e).__name__}: {e}); retrying the {len(keep)} samples in groups of {size}")
+                pending = [list(range(i, min(i + size, len(keep)))) for i in range(0, len(keep), size)]
+                while pending:
+                    rs = pending.pop(0)
                     try:
-                        out = model.generate([prompts[r]], video_spatio_temporal_features=feats[r][None], do_sample=False,
-                                             max_new_tokens=args.max_new_tokens, stop_strings=[stops[r]], tokenizer=tokenizer).cpu()
-                        record(j, out[0], len(prompts[r]))
+                        out = model.generate([prompts[r] for r in rs], video_spatio_temporal_features=torch.stack([feats[r] for r in rs]), do_sample=False,
+                                             max_new_tokens=args.max_new_tokens, stop_strings=[stops[r] for r in rs], tokenizer=tokenizer).cpu()
+                        for q, r in enumerate(rs):
+                            record(keep[r], out[q], len(prompts[r]))
                     except Exception as e1:                            # noqa: BLE001
-                        print(f"Error processing video file '{tasks[indices[j]]['name']}': {e1}")
+                        if len(rs) > 1:                                # still too big (or one bad sample inside): split again
+                            pending[:0] = [rs[:len(rs) // 2], rs[len(rs) // 2:]]
+                        else:
+                            print(f"Error processing video file '{tasks[indices[keep[rs[0]]]]['name']}': {e1}")
         if tfile:
             n_fresh = sum(1 for f in clips.values() if not isinstance(f, (Exception, _Cached)))
             for j, idx in enumerate(indices):
