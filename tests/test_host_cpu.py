@@ -391,6 +391,35 @@ def test_collective_identity_refuses_shared_devices_and_parses_the_rccl_log(tmp_
     assert parallel.rccl_transport(cleanup=False)["verdict"] == "SHM"
 
 
+def test_kv_reuse_prefix_rules():
+    """generate(kv_reuse_key=...) (round 6; a later chat turn prefills only what is behind the cached prefix, reference chat.py:108-160 re-runs the
+    whole conversation): which prefix of the cache a new prompt may start from -- host logic, checked here on a stub without a device."""
+    from video_llava_amd.model.video_chatgpt import VideoChatGPTLlamaForCausalLM as M, VisionConfig
+
+    class Stub:
+        pass
+    m = Stub()
+    m.model = Stub()
+    vc = m.model.vision_config = VisionConfig()
+    vc.vid_patch_token, vc.vid_start_token, vc.vid_end_token = 900, 901, 902
+    kvh = object()
+    cached = [1, 7, 8, 901, 900, 900, 902, 9, 10, 11, 40, 41, 42]        # prompt (with the video run) + the answer tokens that were fed back
+    m._kv = {(1, 64): kvh}
+    m._reuse = ("clip-a", kvh, 64, cached)
+    f = lambda key, ids, new=8: M._reusable_prefix(m, key, ids, new)
+    assert f("clip-a", cached + [50, 51]) == len(cached)                  # the new prompt extends the cache: everything is kept
+    assert f("clip-a", cached[:10] + [60, 61, 62]) == 10                   # the answer came back re-tokenised: common prefix only
+    assert f("clip-a", list(cached)) == len(cached) - 1                    # nothing new: one token still has to run (its logits pick the next)
+    assert f("clip-b", cached + [50]) == 0                                 # another clip's conversation
+    assert f("clip-a", [1, 7, 99] + cached[3:] + [50]) == 0                # diverges before the video run: the run would lie in the appended part
+    assert f("clip-a", cached[:5]) == 0                                    # cut inside the video run
+    assert f("clip-a", cached + [50], new=64) == 0                         # would outgrow the cache
+    m._kv = {(1, 64): object()}
+    assert f("clip-a", cached + [50]) == 0                                 # the cache the record points at is gone
+    m._reuse = None
+    assert f("clip-a", cached + [50]) == 0
+
+
 @pytest.mark.parametrize("rel", ["bench.py", "video_llava_amd/benchlib.py", "__graft_entry__.py"])
 def test_measurement_scripts_have_no_undefined_names(rel):
     """bench.py's CPU-baseline child only runs at the end of a GPU bench (it builds a 27 GB fp32 model), so a name that went missing in a refactor
