@@ -427,6 +427,8 @@ class Workload:
         roofline["share_of_step"] = d["ms_per_step_est"] / ms_per_step
         roofline["algorithmic_bytes_per_launch"] = raw[dom]["bytes"] / raw[dom]["launches"] if raw[dom]["bytes"] > 0 else None
         tag = "traffic" if (a.llm == "7b" and a.weights == "16bit" and a.image == 224) else (f"{a.llm}_{a.weights}" if a.image == 224 else f"image{a.image}")
+        if a.clips_per_gpu != 8:                      # wide batches launch other kernel shapes: their own PMC file or no traffic figure at all
+            tag = f"clips{a.clips_per_gpu}" if tag == "traffic" else f"{tag}_clips{a.clips_per_gpu}"
         roofline.update(pmc_traffic(dom, tag))
         if a.workload == "full":
             try:
@@ -451,7 +453,8 @@ class Workload:
             g = fam["decode_gemv"]
             self.roofline_gemv = {"kernel": "decode_gemv", "bound": "hbm", "achieved": g["gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": g["gbs"] / PEAK_HBM_GBS,
                                   "avg_launch_us": g["avg_us"], "launches_per_step": g["launches_per_step"], "share_of_step": g["ms_per_step_est"] / ms_per_step,
-                                  "algorithmic_bytes_per_launch": raw["decode_gemv"]["bytes"] / raw["decode_gemv"]["launches"], "traffic": None}
+                                  "algorithmic_bytes_per_launch": raw["decode_gemv"]["bytes"] / raw["decode_gemv"]["launches"]}
+            self.roofline_gemv.update(pmc_traffic("decode_gemv", tag))
         return fam, roofline
 
     def free(self):
