@@ -396,7 +396,9 @@ def test_kv_bounds_and_errors(ctx):
                                         # three (gate, up) pairs per workgroup (688 pairs: a ragged last workgroup), lm_head with eight row blocks
                                         # (2001 row blocks: seven tiles past the matrix in the last workgroup), at two and four column tiles
                                         (2, 22016, 4096, 64), (2, 22016, 4096, 19), (3, 32003, 4096, 40), (3, 32003, 4096, 12), (0, 12288, 4096, 64),
-                                        (1, 4096, 4096, 33)])
+                                        (1, 4096, 4096, 33),
+                                        # ... and the 13B shapes: gate/up with four pairs per workgroup (864 pairs -> 216 workgroups), qkv with four row blocks
+                                        (2, 27648, 5120, 64), (2, 27648, 5120, 24), (0, 15360, 5120, 64), (0, 15360, 5120, 17)])
 def test_gemv_building_block(ctx, dtype, tol, mode, N, K, B):
     """pgv_gemv on fragment-blocked weights (pgv_pack_blocked) vs torch fp32, every epilogue mode."""
     from video_llava_amd import _lib
@@ -654,6 +656,50 @@ def test_full_7b_wide_batch_invariance(ctx, B, weights):
         kv1, nxt, lg = m.prefill([prompts[i]], feats[i:i + 1], 512, want_logits=True)
         for t in range(n):
             assert torch.equal(lg[0], steps_b[t][1][i]), (weights, B, i, t)
+            assert int(nxt[0]) == int(steps_b[t][0][i])
+            if t + 1 < n:
+                nxt, lg = m.decode_step(kv1, nxt, want_logits=True)
+        del kv1
+
+
+@pytest.mark.parametrize("B", [12, 24, 64])
+def test_13b_shaped_wide_batch_invariance(ctx, B):
+    """The 13B launch shapes of the wide batches (round 6: qkv with four row blocks per workgroup, gate/up with FOUR (gate, up) pairs -- 864 pairs -> 216
+    workgroups --, lm_head with eight row blocks, the blocked activation layout at hidden 5120, the 10-row-block 8-phase producers) inside the
+    whole decode chain: a 2-layer 13B-shaped bf16 model, ragged prompts with 356 video rows; logits of prefill + 4 decode steps of sequences
+    0, B / 2 + 1 and B - 1 inside the batch are BITWISE those of the sequence decoded alone (whose launch shapes are the narrow ones, checked against
+    the oracle by test_7b_shaped_two_layers_vs_oracle), and the graph-replayed greedy loop returns the stepwise tokens."""
+    from video_llava_amd import random_init as ri
+    from video_llava_amd.model.video_chatgpt import VideoChatGPTConfig, VideoChatGPTLlamaForCausalLM, VisionConfig
+    vocab = 32003
+    cfg = VideoChatGPTConfig(vocab_size=vocab, hidden_size=5120, intermediate_size=13824, num_hidden_layers=2, num_attention_heads=40, eos_token_id=None)
+    m = VideoChatGPTLlamaForCausalLM(cfg, VisionConfig(frame_size=224), torch.bfloat16, torch.device(DEV))
+    ri.load_streaming(m, ri.iter_llama_tensors(vocab=vocab, hidden=5120, inter=13824, layers=2, device=DEV, dtype=torch.bfloat16, seed=13, head_std=0.05))
+    vc = m.get_model().vision_config
+    vc.vid_patch_token, vc.vid_start_token, vc.vid_end_token, vc.use_vid_start_end = vocab - 3, vocab - 2, vocab - 1, True
+    rng = np.random.default_rng(20 + B)
+    V = 356
+    prompts = [[1] + rng.integers(3, vocab - 3, 30 + int(rng.integers(0, 40))).tolist() + [vocab - 2] + [vocab - 3] * V + [vocab - 1]
+               + rng.integers(3, vocab - 3, 5).tolist() for _ in range(B)]
+    feats = torch.from_numpy(rng.standard_normal((B, V, 1024)).astype(np.float32) * 0.5).to(torch.float16).to(DEV)
+    n = 5
+    kv, nxt_b, lg_b = m.prefill(prompts, feats, 512, want_logits=True)
+    first = nxt_b.clone()
+    steps_b = [(nxt_b.clone(), lg_b.clone())]
+    for _ in range(n - 1):
+        nxt_b, lg_b = m.decode_step(kv, nxt_b, want_logits=True)
+        steps_b.append((nxt_b.clone(), lg_b.clone()))
+    assert torch.isfinite(steps_b[-1][1]).all()
+    kv, nxt2, _ = m.prefill(prompts, feats, 512)
+    assert torch.equal(nxt2, first)
+    toks = m.decode_greedy(kv, nxt2, n - 1)
+    for t in range(1, n):
+        assert torch.equal(toks[:, t - 1], steps_b[t][0]), t
+    del kv
+    for i in (0, B // 2 + 1, B - 1):
+        kv1, nxt, lg = m.prefill([prompts[i]], feats[i:i + 1], 512, want_logits=True)
+        for t in range(n):
+            assert torch.equal(lg[0], steps_b[t][1][i]), (B, i, t)
             assert int(nxt[0]) == int(steps_b[t][0][i])
             if t + 1 < n:
                 nxt, lg = m.decode_step(kv1, nxt, want_logits=True)

@@ -748,10 +748,12 @@ static const GemvShape kGemvShapes[] = {
     gemv_shape<GV_STORE16, 1, 1>(), gemv_shape<GV_STORE16, 3, 1>(), gemv_shape<GV_STORE16, 4, 1>(), gemv_shape<GV_RESID, 1, 1>(), gemv_shape<GV_SWIGLU, 2, 1>(),
     gemv_shape<GV_F32, 1, 1>(), gemv_shape<GV_F32, 8, 1>(), gemv_shape<GV_RESIDNORM, 1, 1>(),
     // 2 / 4 column tiles (B <= 32 / 64)
-    gemv_shape<GV_STORE16, 1, 2>(), gemv_shape<GV_STORE16, 3, 2>(), gemv_shape<GV_RESID, 1, 2>(), gemv_shape<GV_SWIGLU, 2, 2>(), gemv_shape<GV_SWIGLU, 4, 2>(),
-    gemv_shape<GV_SWIGLU, 6, 2>(), gemv_shape<GV_F32, 1, 2>(), gemv_shape<GV_F32, 8, 2>(), gemv_shape<GV_RESIDNORM, 1, 2>(),
-    gemv_shape<GV_STORE16, 1, 4>(), gemv_shape<GV_STORE16, 3, 4>(), gemv_shape<GV_RESID, 1, 4>(), gemv_shape<GV_SWIGLU, 2, 4>(), gemv_shape<GV_SWIGLU, 4, 4>(),
-    gemv_shape<GV_SWIGLU, 6, 4>(), gemv_shape<GV_F32, 1, 4>(), gemv_shape<GV_F32, 8, 4>(), gemv_shape<GV_RESIDNORM, 1, 4>(),
+    gemv_shape<GV_STORE16, 1, 2>(), gemv_shape<GV_STORE16, 3, 2>(), gemv_shape<GV_STORE16, 4, 2>(), gemv_shape<GV_RESID, 1, 2>(), gemv_shape<GV_SWIGLU, 2, 2>(),
+    gemv_shape<GV_SWIGLU, 4, 2>(), gemv_shape<GV_SWIGLU, 6, 2>(), gemv_shape<GV_SWIGLU, 8, 2>(), gemv_shape<GV_F32, 1, 2>(), gemv_shape<GV_F32, 8, 2>(),
+    gemv_shape<GV_RESIDNORM, 1, 2>(),
+    gemv_shape<GV_STORE16, 1, 4>(), gemv_shape<GV_STORE16, 3, 4>(), gemv_shape<GV_STORE16, 4, 4>(), gemv_shape<GV_RESID, 1, 4>(), gemv_shape<GV_SWIGLU, 2, 4>(),
+    gemv_shape<GV_SWIGLU, 4, 4>(), gemv_shape<GV_SWIGLU, 6, 4>(), gemv_shape<GV_SWIGLU, 8, 4>(), gemv_shape<GV_F32, 1, 4>(), gemv_shape<GV_F32, 8, 4>(),
+    gemv_shape<GV_RESIDNORM, 1, 4>(),
 };
 
 // The 8-phase form of a residual producer with CT column tiles and NWB row blocks (= waves) per workgroup; `a` is complete except lds_bytes.
@@ -804,6 +806,9 @@ static GemvChoice choose_gemv(int mode, bool w8, int B, int grid, int K, int num
         // Wide batches re-read 2 - 4 x the activation lines per workgroup, so the row blocks that share them matter more: qkv 3, gate/up two
         // (gate, up) pairs when the block counts divide.
         if (mode == GV_STORE16 && grid % 3 == 0) c.tl = 3;
+        // ... four where three leave a ragged second round and four fill one (13B qkv: 960 row blocks -> 320 workgroups = 1 1/4 rounds with three,
+        // 240 with four -- the choice the narrow batches make below, for the same reason)
+        if (mode == GV_STORE16 && lab_switch("PGV_GEMV_WIDE_QKV4", 1) != 0 && grid % 4 == 0 && grid / 4 <= num_cu && (grid % 3 != 0 || grid / 3 > num_cu)) c.tl = 4;
         // (four column tiles: 228 VGPRs once the sum-of-squares partials are requested after the weight loop, SSQ_LATE)
         if (mode == GV_SWIGLU) c.tl = (grid % 2 == 0 && (B <= 32 || lab_switch("PGV_GEMV_WIDE_TL4", 1) != 0)) ? 4 : 2;
         // A wide workgroup holds a CU to itself (its registers and the LDS of its partial tiles), so the launch runs in ROUNDS of num_cu workgroups
@@ -811,6 +816,8 @@ static GemvChoice choose_gemv(int mode, bool w8, int B, int grid, int K, int num
         // two rounds (88 CUs run a second workgroup, the others wait: 50.9 us at 64 sequences), 230 workgroups of THREE pairs = one round and a third
         // fewer reads of x (LAB.md round 6).  Taken when three pairs per workgroup fit one round and two do not.
         if (mode == GV_SWIGLU && !w8 && lab_switch("PGV_GEMV_WIDE_TL6", 1) != 0 && (grid + 2) / 3 <= num_cu && (grid + 1) / 2 > num_cu) c.tl = 6;
+        // ... four pairs where three still need a second round (13B gate/up: 864 pairs -> 288 workgroups of three, 216 of four)
+        else if (mode == GV_SWIGLU && !w8 && lab_switch("PGV_GEMV_WIDE_TL8", 1) != 0 && (grid + 3) / 4 <= num_cu && (grid + 1) / 2 > num_cu) c.tl = 8;
         // lm_head: 2001 row blocks; one per workgroup means 2001 passes over the activation operand (512 KB each against 128 KB of weights: 102 us at
         // 64 sequences).  Eight per workgroup: 251 workgroups, one round.
         if (mode == GV_F32 && !w8 && lab_switch("PGV_GEMV_WIDE_HEAD8", 1) != 0 && (grid + 7) / 8 <= num_cu) c.tl = 8;
