@@ -462,7 +462,12 @@ def test_fp8_quantizer_matches_cpu_twin(ctx, dtype, N, K):
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("mode,N,K,B", [(0, 1536, 512, 3), (1, 512, 768, 8), (2, 1536, 512, 16), (3, 512, 1024, 5), (0, 12288, 4096, 8), (2, 22016, 4096, 8)])
+@pytest.mark.parametrize("mode,N,K,B", [(0, 1536, 512, 3), (1, 512, 768, 8), (2, 1536, 512, 16), (3, 512, 1024, 5), (0, 12288, 4096, 8), (2, 22016, 4096, 8),
+                                        # the wide launch shapes with fp8 weights (round 6: weights buffered per 64-column group, x per k-block): gate/up with three
+                                        # pairs per workgroup at 2 / 4 column tiles, four pairs (13B), a ragged last workgroup over K = 192 (waves 3 .. 7 hold no
+                                        # group at all, every wave's second group lies past the end of K), lm_head with eight row blocks at 1 / 2 / 4 column tiles
+                                        (2, 22016, 4096, 64), (2, 22016, 4096, 24), (2, 27648, 5120, 64), (2, 27648, 5120, 30), (2, 19264, 192, 40),
+                                        (3, 32000, 4096, 64), (3, 32000, 4096, 20), (3, 32000, 4096, 12), (3, 4000, 512, 40)])
 def test_gemv_fp8_bit_equal_to_16bit_on_dequantised(ctx, dtype, mode, N, K, B):
     from video_llava_amd import _lib
     g = torch.Generator().manual_seed(N + K + B + 1)
@@ -662,11 +667,11 @@ def test_full_7b_wide_batch_invariance(ctx, B, weights):
         del kv1
 
 
-@pytest.mark.parametrize("B", [12, 24, 64])
-def test_13b_shaped_wide_batch_invariance(ctx, B):
+@pytest.mark.parametrize("B,weights", [(12, "bf16"), (24, "bf16"), (64, "bf16"), (24, "fp8"), (64, "fp8")])
+def test_13b_shaped_wide_batch_invariance(ctx, B, weights):
     """The 13B launch shapes of the wide batches (round 6: qkv with four row blocks per workgroup, gate/up with FOUR (gate, up) pairs -- 864 pairs -> 216
-    workgroups --, lm_head with eight row blocks, the blocked activation layout at hidden 5120, the 10-row-block 8-phase producers) inside the
-    whole decode chain: a 2-layer 13B-shaped bf16 model, ragged prompts with 356 video rows; logits of prefill + 4 decode steps of sequences
+    workgroups --, lm_head with eight row blocks, the blocked activation layout at hidden 5120, the 10-row-block 8-phase producers; the same shapes with fp8
+    weights) inside the whole decode chain: a 2-layer 13B-shaped bf16 model, ragged prompts with 356 video rows; logits of prefill + 4 decode steps of sequences
     0, B / 2 + 1 and B - 1 inside the batch are BITWISE those of the sequence decoded alone (whose launch shapes are the narrow ones, checked against
     the oracle by test_7b_shaped_two_layers_vs_oracle), and the graph-replayed greedy loop returns the stepwise tokens."""
     from video_llava_amd import random_init as ri
@@ -675,6 +680,8 @@ def test_13b_shaped_wide_batch_invariance(ctx, B):
     cfg = VideoChatGPTConfig(vocab_size=vocab, hidden_size=5120, intermediate_size=13824, num_hidden_layers=2, num_attention_heads=40, eos_token_id=None)
     m = VideoChatGPTLlamaForCausalLM(cfg, VisionConfig(frame_size=224), torch.bfloat16, torch.device(DEV))
     ri.load_streaming(m, ri.iter_llama_tensors(vocab=vocab, hidden=5120, inter=13824, layers=2, device=DEV, dtype=torch.bfloat16, seed=13, head_std=0.05))
+    if weights == "fp8":
+        m.quantize_weights_fp8()
     vc = m.get_model().vision_config
     vc.vid_patch_token, vc.vid_start_token, vc.vid_end_token, vc.use_vid_start_end = vocab - 3, vocab - 2, vocab - 1, True
     rng = np.random.default_rng(20 + B)

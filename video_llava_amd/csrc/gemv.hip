@@ -109,8 +109,12 @@ __global__ __launch_bounds__(kGemvWaves * 64) void gemv_mfma_kernel(GemvArgs p) 
     static_assert(!X2 || CT == 1, "the merged x load uses the lanes of columns 8..15");
     // HS (six row blocks and more): the weight stream is pipelined in HALF groups (one 32-column k-block per register buffer) -- a whole group of
     // six row blocks x four column tiles would not fit the register file next to its 96 accumulator registers.  Same order of the MFMAs.
-    constexpr bool HS = (TL >= 6);
+    constexpr bool HS = (TL >= 6) && !W8;
     static_assert(!HS || (!W8 && PU == 1 && !X2), "half-group pipelining: 16-bit weights, one group per buffer");
+    // HS8: the same for fp8 weights.  An fp8 group (64 columns) is ONE 16-byte load per lane and row block, so the weights are buffered per group and
+    // only the x fragments per k-block: 2 x (TL + CT) x 4 buffer registers instead of 2 x (TL + 2 CT) x 4.  Same order of the MFMAs.
+    constexpr bool HS8 = (TL >= 6) && W8;
+    static_assert(!HS8 || (PU == 1 && !X2), "half-group x pipelining: one group per buffer");
     static_assert(MODE != GV_RESIDNORM || TL == 1, "a residual producer owns one row block");
     // The partial tiles of the NW waves meet in LDS, at most 16 tiles (128 KB) at a time: CTR column tiles per round.
     constexpr int CTR = (TILES * CT <= 16) ? CT : (16 / TILES);
@@ -240,6 +244,82 @@ __global__ __launch_bounds__(kGemvWaves * 64) void gemv_mfma_kernel(GemvArgs p) 
         __builtin_amdgcn_sched_barrier(0);
         mmah(wa, xa, i, true);
         mmah(wb, xb, i + 1, true);
+    } else if constexpr (HS8) {
+        // group gi of this wave = 64 columns w + NW * gi, gi = 0 .. ng - 1 (every wave runs ng = ceil(groups / NW) of them); step 2 gi + h multiplies
+        // k-block h of the group.  A group past the end of K re-reads the last one against x fragments requested OUTSIDE the buffer descriptor
+        // (all-zero, no request): exact zeros, no predicated loads, no select in front of the MFMAs.
+        const int j_end = p.K >> 6;                               // fp8 weights: K % 64 == 0
+        const int ng = ((j_end + NW - 1) / NW + 1) & ~1;         // groups per wave, rounded up to whole PAIRS (hidden 4096 / 5120: 8 / 10, nothing added)
+        // (row block, group) addresses are wave-uniform: scalar base + one shared 32-bit lane offset per load, no per-tile pointer registers
+        const unsigned lane_off = (unsigned)lane * 16u;
+        auto loadw = [&](u32x4_t (&wf)[TILES], int gi) {
+            const int g = min(w + NW * gi, j_end - 1);
+            if (!GV_ABL(p, 4)) {
+#pragma unroll
+                for (int t = 0; t < TILES; ++t) {
+                    const char* sp = p.W + ((size_t)rb[t] * j_end + g) * 1024;
+                    wf[t] = __builtin_nontemporal_load((const u32x4_t*)(sp + lane_off));
+                }
+            }
+        };
+        auto loadx = [&](typename T::v8 (&xf)[CT], int gi, int h) {
+            const int g = w + NW * gi;
+            const bool past = g >= j_end;                         // wave-uniform
+            if (!GV_ABL(p, 1)) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+                    xf[ct] = __builtin_bit_cast(typename T::v8, __builtin_amdgcn_raw_buffer_load_b128(xrs, past ? 0x80000000u : xvo[ct] + (unsigned)(2 * g + h) * xkb, 0, 0));
+            }
+        };
+        auto mma8 = [&](u32x4_t (&wf)[TILES], typename T::v8 (&xf)[CT], int h) {
+#pragma unroll
+            for (int t = 0; t < TILES; ++t) {
+                const typename T::v8 wv = fp8x8_to_v8<T>(wf[t][2 * h], wf[t][2 * h + 1]);      // widened once, used by every column tile
+                if (GV_ABL(p, 2)) {
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) acc[t][ct][0] += (float)wv[0] + (float)xf[ct][0];
+                    continue;
+                }
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) acc[t][ct] = T::mfma16(wv, xf[ct], acc[t][ct]);
+            }
+        };
+        u32x4_t wa[TILES] = {}, wb[TILES] = {};
+        typename T::v8 xa[CT] = {}, xb[CT] = {};
+        loadw(wa, 0);
+        loadx(xa, 0, 0);
+        int gi = 0;
+        for (; gi + 2 < ng; gi += 2) {
+            loadx(xb, gi, 1); loadw(wb, gi + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma8(wa, xa, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            loadx(xa, gi + 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma8(wa, xb, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            loadx(xb, gi + 1, 1); loadw(wa, gi + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mma8(wb, xa, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            loadx(xa, gi + 2, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma8(wb, xb, 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // the last two groups: wa / xa hold group gi, k-block 0
+        loadx(xb, gi, 1); loadw(wb, gi + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma8(wa, xa, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        loadx(xa, gi + 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma8(wa, xb, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        loadx(xb, gi + 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma8(wb, xa, 0);
+        mma8(wb, xb, 1);
     } else {
         // groups (64 columns) j_lo + w + NW * g, g = 0 .. : batch b holds g = b * PU .. b * PU + PU - 1.  Every batch but the last is complete
         // for every wave (the waves' group counts differ by at most one); in the last batch, entries past the end re-read the last valid
@@ -737,8 +817,8 @@ struct GemvShape {
 };
 template <int MODE, int TL, int CT>
 constexpr GemvShape gemv_shape() {
-    if constexpr (TL >= 6)                       // half-group pipelining: 16-bit weights only (an fp8 group is ONE load per lane)
-        return {MODE, TL, CT, {{&launch_variant<MODE, false, TL, false, CT>, nullptr}, {nullptr, nullptr}}};
+    if constexpr (TL >= 6)                       // six row blocks and more: no merged x load (half-group pipelining for 16-bit weights; an fp8 group is ONE load per lane: whole groups)
+        return {MODE, TL, CT, {{&launch_variant<MODE, false, TL, false, CT>, nullptr}, {&launch_variant<MODE, true, TL, false, CT>, nullptr}}};
     else
         return {MODE, TL, CT, {{&launch_variant<MODE, false, TL, false, CT>, x2_variant<MODE, false, TL, CT>()},
                                {&launch_variant<MODE, true, TL, false, CT>, x2_variant<MODE, true, TL, CT>()}}};
@@ -815,12 +895,12 @@ static GemvChoice choose_gemv(int mode, bool w8, int B, int grid, int K, int num
         // and every workgroup moves the whole activation operand through its CU: 7B gate/up = 688 (gate, up) pairs -> 344 workgroups of two pairs =
         // two rounds (88 CUs run a second workgroup, the others wait: 50.9 us at 64 sequences), 230 workgroups of THREE pairs = one round and a third
         // fewer reads of x (LAB.md round 6).  Taken when three pairs per workgroup fit one round and two do not.
-        if (mode == GV_SWIGLU && !w8 && lab_switch("PGV_GEMV_WIDE_TL6", 1) != 0 && (grid + 2) / 3 <= num_cu && (grid + 1) / 2 > num_cu) c.tl = 6;
+        if (mode == GV_SWIGLU && (!w8 || lab_switch("PGV_GEMV_WIDE_FP8", 1) != 0) && lab_switch("PGV_GEMV_WIDE_TL6", 1) != 0 && (grid + 2) / 3 <= num_cu && (grid + 1) / 2 > num_cu) c.tl = 6;
         // ... four pairs where three still need a second round (13B gate/up: 864 pairs -> 288 workgroups of three, 216 of four)
-        else if (mode == GV_SWIGLU && !w8 && lab_switch("PGV_GEMV_WIDE_TL8", 1) != 0 && (grid + 3) / 4 <= num_cu && (grid + 1) / 2 > num_cu) c.tl = 8;
+        else if (mode == GV_SWIGLU && (!w8 || lab_switch("PGV_GEMV_WIDE_FP8", 1) != 0) && lab_switch("PGV_GEMV_WIDE_TL8", 1) != 0 && (grid + 3) / 4 <= num_cu && (grid + 1) / 2 > num_cu) c.tl = 8;
         // lm_head: 2001 row blocks; one per workgroup means 2001 passes over the activation operand (512 KB each against 128 KB of weights: 102 us at
         // 64 sequences).  Eight per workgroup: 251 workgroups, one round.
-        if (mode == GV_F32 && !w8 && lab_switch("PGV_GEMV_WIDE_HEAD8", 1) != 0 && (grid + 7) / 8 <= num_cu) c.tl = 8;
+        if (mode == GV_F32 && (!w8 || lab_switch("PGV_GEMV_WIDE_FP8", 1) != 0) && lab_switch("PGV_GEMV_WIDE_HEAD8", 1) != 0 && (grid + 7) / 8 <= num_cu) c.tl = 8;
         // narrow matrices (o_proj, down_proj): 8 row blocks x K phase per workgroup + a finish launch where it pays (kernel trace at 32 clips:
         // down_proj 32.0 -> 22.4 + 4.9 us (finish), o_proj 13.3 -> 9.6 + 4.9: the short-K matrix only gains once the batch spans four tiles)
         if (mode == GV_RESIDNORM) c.k8 = k8_ok && (K / 64) >= 16 && (B > 32 || K >= 8192);
@@ -842,7 +922,7 @@ static GemvChoice choose_gemv(int mode, bool w8, int B, int grid, int K, int num
         case GV_F32:
             // lm_head at 9 .. 16 sequences: 2001 workgroups of one row block each read the whole activation operand (128 KB against 128 KB of
             // weights); eight row blocks per workgroup as at the wide batches (251 workgroups, one round)
-            if (!w8 && B > 8 && lab_switch("PGV_GEMV_WIDE_HEAD8", 1) != 0 && (grid + 7) / 8 <= num_cu) c.tl = 8;
+            if ((!w8 || lab_switch("PGV_GEMV_WIDE_FP8", 1) != 0) && B > 8 && lab_switch("PGV_GEMV_WIDE_HEAD8", 1) != 0 && (grid + 7) / 8 <= num_cu) c.tl = 8;
             break;
         case GV_RESIDNORM:
             // fp8 down_proj of the 13B shapes (K = 13 824, 320 row blocks): a 16-row workgroup requests as many activation lines as weight lines
