@@ -121,6 +121,8 @@ def bench_decode_wide(ctx, dtype=torch.bfloat16):
     shapes = ((0, 12288, 4096, "qkv"), (2, 22016, 4096, "gate/up"), (3, 32003, 4096, "lm_head"))
     if os.environ.get("PGV_WIDE_13B"):
         shapes = ((0, 15360, 5120, "qkv13"), (2, 27648, 5120, "gate/up13"))
+    if os.environ.get("PGV_WIDE_PROD"):                    # the residual producers on the 16-row kernel (mode 1: resid += W x; no 8-phase form): what does blocked x buy them?
+        shapes = ((1, 4096, 4096, "o_proj"), (1, 4096, 11008, "down"), (1, 5120, 5120, "o_proj13"), (1, 5120, 13824, "down13"))
     for (mode, N, K, name) in shapes:
         ncopy = max(2, int(600e6 // (N * K * 2)) + 1)
         Np = (N + 15) // 16 * 16
@@ -143,7 +145,9 @@ def bench_decode_wide(ctx, dtype=torch.bfloat16):
                 xp[:B] = x
                 x = xp.view(CT, 16, K // 32, 4, 8).permute(2, 0, 3, 1, 4).contiguous()
                 ldx = K
-            out = torch.empty(B, N, device=DEV) if mode == 3 else torch.empty(B, N // 2 if mode == 2 else N, device=DEV, dtype=dtype)
+            out = torch.empty(B, N, device=DEV) if mode in (1, 3) else torch.empty(B, N // 2 if mode == 2 else N, device=DEV, dtype=dtype)
+            if mode == 1:
+                out.zero_()
             state = {"i": 0}
 
             def f():
