@@ -391,6 +391,37 @@ def test_collective_identity_refuses_shared_devices_and_parses_the_rccl_log(tmp_
     assert parallel.rccl_transport(cleanup=False)["verdict"] == "SHM"
 
 
+def test_chat_turn_bookkeeping_follows_the_reference_rules(capsys):
+    """Host logic of the chat front end without a device (reference video_chatgpt/chat.py:90-104 add_text, :201-222 print_state / _post_process_code):
+    the first turn of a clip is cut at 1200 characters, gets the `<video>` marker once and carries the clip path; later turns are cut at 1536 and
+    carry nothing; every turn queues a (user, text) and an open (assistant, None) message; escapes inside paired code fences are undone."""
+    from types import SimpleNamespace as NS
+    from video_llava_amd.chat import VideoChatGPTInterface
+    from video_llava_amd.video_conversation import default_conversation
+    model = NS(get_model=lambda: NS(vision_config=NS(use_vid_start_end=True)))
+    iface = VideoChatGPTInterface(None, None, components=(model, None, None, NS(crop_size={"height": 224, "width": 224}), 356))
+    assert iface.replace_token.count("<vid_patch>") == 356 and iface.replace_token.startswith("<vid_start>") and iface.replace_token.endswith("<vid_end>")
+    iface.add_text("q" * 2000, "clip.mp4")
+    (role_u, first), (role_a, open_slot) = iface.state.messages[-2:]
+    assert (role_u, role_a) == tuple(default_conversation.roles[:2]) and open_slot is None
+    assert first == ("q" * 1200 + "\n<video>", "clip.mp4") and iface.state.skip_next is False
+    iface.first_run = False                                      # what answer() does after the first turn
+    iface.add_text("<video> again " + "r" * 2000, "clip.mp4")
+    assert iface.state.messages[-2][1] == ("<video> again " + "r" * 2000)[:1536] and iface.state.messages[-1][1] is None
+    n0 = len(default_conversation.messages)                      # the template's own example exchange
+    assert len(iface.state.messages) == n0 + 4
+    iface.clear_history()
+    iface.add_text("what is <video> about", None)                # the marker is not added twice
+    assert iface.state.messages[-2][1] == ("what is <video> about", None) and len(iface.state.messages) == n0 + 2
+    iface.print_state()
+    out = capsys.readouterr().out
+    assert out.startswith("SYSTEM: " + str(default_conversation.system)) and f"{default_conversation.roles[0]}: what is <video> about" in out
+    post = VideoChatGPTInterface._post_process_code
+    assert post("no fences \\_") == "no fences \\_"
+    assert post("a\n```py\nx\\_y\n```\nb\\_") == "a\n```py\nx_y\n```\nb\\_"
+    assert post("a\n```py\nx\\_y") == "a\n```py\nx\\_y"        # an unpaired fence: untouched
+
+
 def test_kv_reuse_prefix_rules():
     """generate(kv_reuse_key=...) (round 6; a later chat turn prefills only what is behind the cached prefix, reference chat.py:108-160 re-runs the
     whole conversation): which prefix of the cache a new prompt may start from -- host logic, checked here on a stub without a device."""

@@ -71,19 +71,21 @@ class VideoChatGPTInterface:
         self.transcript_text = None
 
     def add_text(self, text, video_path):
-        if len(text) <= 0 and video_path is None:
-            self.state.skip_next = True
-        text = text[:1536]                                   # hard cut-off (:93)
+        """Queue one user turn (reference :90-104): empty input without a clip is skipped; a turn is cut at 1536 characters, the first turn of a
+        clip at 1200 and carries the `<video>` (and, with ASR, `<audio_transcript>`) markers and the clip path."""
+        self.state.skip_next = (not text) and video_path is None      # (overwritten below exactly like the reference: the turn is queued either way)
+        limit = 1200 if self.first_run else 1536
+        turn = text[:limit]
         if self.first_run:
-            text = text[:1200]                               # hard cut-off for videos (:95)
-            if "<video>" not in text:
-                text = text + "\n<video>"
+            if "<video>" not in turn:
+                turn += "\n<video>"
             if self.use_asr:
-                text = text + "\n<audio_transcript>"
-            text = (text, video_path)
+                turn += "\n<audio_transcript>"
+            turn = (turn, video_path)
             self.state = default_conversation.copy()
-        self.state.append_message(self.state.roles[0], text)
-        self.state.append_message(self.state.roles[1], None)
+        user, assistant = self.state.roles[0], self.state.roles[1]
+        self.state.append_message(user, turn)
+        self.state.append_message(assistant, None)
         self.state.skip_next = False
 
     def answer(self):
@@ -92,11 +94,10 @@ class VideoChatGPTInterface:
         if self.video_features is None:
             raise RuntimeError("upload_video() first")
         if self.first_run:                                   # re-root the first turn on the chosen template (:113-120)
-            curr_state = self.state
-            new_state = conv_templates[self.conv_mode].copy()
-            new_state.append_message(new_state.roles[0], curr_state.messages[-2][1])
-            new_state.append_message(new_state.roles[1], None)
-            self.state = new_state
+            first_user_turn = self.state.messages[-2][1]
+            self.state = conv_templates[self.conv_mode].copy()
+            self.state.append_message(self.state.roles[0], first_user_turn)
+            self.state.append_message(self.state.roles[1], None)
             self.first_run = False
         prompt = self.state.get_prompt()
         prompt = prompt.replace("<video>", self.replace_token, 1)
@@ -123,46 +124,38 @@ class VideoChatGPTInterface:
         return output
 
     def interact(self):
+        """Terminal loop (reference :173-199): ask for a clip, then turns until an empty line (new conversation) or Ctrl-C (quit)."""
         print("Welcome to PG-Video-LLaVA !")
-        video_set = False
-        video_path = None
-        while True:
-            if not video_set:
-                video_path = input("Please enter the video file path:   ")
-                self.upload_video(video_path)
-                video_set = True
-            try:
+        clip = None
+        try:
+            while True:
+                if clip is None:
+                    clip = input("Please enter the video file path:   ")
+                    self.upload_video(clip)
                 text = input("USER>>")
-                if not text:
+                if text:
+                    self.add_text(text, clip)
+                    print("ASSISTANT>>", self.answer())
+                else:                                        # empty line: drop the conversation and ask for the next clip
                     print("----------\n\n")
                     self.clear_history()
-                    video_set = False
-                    continue
-                self.add_text(text, video_path)
-                print("ASSISTANT>>", self.answer())
-            except KeyboardInterrupt:
-                print("----------")
-                print("QUITTING...")
-                return
+                    clip = None
+        except KeyboardInterrupt:
+            print("----------\nQUITTING...")
 
     def print_state(self):
-        txt = "SYSTEM: " + str(self.state.system) + "\n"
-        for role, msg in self.state.messages:
-            if type(msg) is tuple:
-                msg, _ = msg
-            txt += str(role) + ": " + str(msg) + "\n"
-        print(txt)
+        lines = [f"SYSTEM: {self.state.system}"]
+        lines += [f"{role}: {msg[0] if type(msg) is tuple else msg}" for role, msg in self.state.messages]
+        print("\n".join(lines) + "\n")
 
     @staticmethod
     def _post_process_code(code):
-        sep = "\n```"
-        if sep in code:
-            blocks = code.split(sep)
-            if len(blocks) % 2 == 1:
-                for i in range(1, len(blocks), 2):
-                    blocks[i] = blocks[i].replace("\\_", "_")
-            code = sep.join(blocks)
-        return code
+        """Undo the `\\_` escapes inside fenced code blocks when the fences pair up (reference :212-222)."""
+        fence = "\n```"
+        parts = code.split(fence)
+        if len(parts) > 1 and len(parts) % 2 == 1:
+            parts[1::2] = [inner.replace("\\_", "_") for inner in parts[1::2]]
+        return fence.join(parts)
 
 
 def parse_args(argv=None):
