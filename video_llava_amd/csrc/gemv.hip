@@ -619,15 +619,16 @@ __global__ __launch_bounds__(NWB * 64) void gemv_k8_kernel(GemvArgs p, f32x4_t* 
             const int g = min(j + 8 * (gi0 + u), j_end - 1);
 #pragma unroll
             for (int h = 0; h < WH; ++h)
-                wf[u][h] = __builtin_nontemporal_load((const wreg_t*)(wp + (size_t)(W8 ? g : min(2 * g + h, kblocks - 1)) * 1024));
+                if (!GV_ABL(p, 4)) wf[u][h] = __builtin_nontemporal_load((const wreg_t*)(wp + (size_t)(W8 ? g : min(2 * g + h, kblocks - 1)) * 1024));
         }
     };
     for (int pass0 = 0; pass0 < gpw; pass0 += gpp) {
         const int ng = min(gpp, gpw - pass0);
-        wreg_t wa[PU][WH], wb[PU][WH];
+        wreg_t wa[PU][WH] = {}, wb[PU][WH] = {};
         wload(wa, pass0);                                        // the first weight batch is in flight while the x slice is staged
         __syncthreads();                                         // the previous pass has been read by every wave
-        if ((kblocks & 1) == 0) {
+        if (GV_ABL(p, 1)) {
+        } else if ((kblocks & 1) == 0) {
             // LDS-DMA (round 6): one wave-instruction lands 8 rows x 128 B = 1 KiB linearly in LDS, every lane fetching the 16-byte chunk that
             // belongs at its position (the XOR swizzle is applied on the SOURCE side); all instructions of a pass are in flight together.  (The
             // first version loaded 16 bytes per thread into a register and stored it, an L2 round trip per loop iteration: 12 dependent
@@ -656,7 +657,7 @@ __global__ __launch_bounds__(NWB * 64) void gemv_k8_kernel(GemvArgs p, f32x4_t* 
 #pragma unroll
             for (int u = 0; u < PU; ++u) {
                 const int gi = gi0 + u - pass0;
-                if (gi < ng) {
+                if (gi < ng && !GV_ABL(p, 2)) {
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         typename T::v8 wv;
@@ -694,7 +695,8 @@ __global__ __launch_bounds__(NWB * 64) void gemv_k8_kernel(GemvArgs p, f32x4_t* 
     }
     f32x4_t* dst = part + (((size_t)rb * 8 + j) * CT) * 64 + lane;
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) dst[ct * 64] = acc[ct];
+    for (int ct = 0; ct < CT; ++ct)
+        if (!GV_ABL(p, 8)) dst[ct * 64] = acc[ct];
 }
 
 // the finish launch: one wave per row block
@@ -847,6 +849,7 @@ static int launch_k8(int dtype, GemvArgs a, int nrb, void* k8_part, hipStream_t 
     a.lds_bytes = lds;
     f32x4_t* part = (f32x4_t*)k8_part;
     PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gemv_k8_kernel<T, W8, CT, NWB>), dim3(nrb / NWB * 8), dim3(NWB * 64), lds, s, a, part));
+    if (GV_ABL(a, 16)) return PGV_OK;
     PGV_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((gemv_k8_finish_kernel<T, W8, CT>), dim3(nrb), dim3(64), 0, s, a, (const f32x4_t*)part));
     return PGV_OK;
 }
@@ -969,6 +972,9 @@ int pgv_launch_gemv(pgv_ctx* ctx, int dtype, int mode, const void* W, const void
     const GemvChoice c = choose_gemv(mode, w8, B, grid, K, ctx->num_cu, norm && norm->k8_part);
     pgv_prof_begin(ctx, 3, s);
     if (c.k8) {
+#ifdef PGV_LAB
+        a.abl = lab_switch("PGV_K8_ABLATE", 0);     // lab: 1 = no x staging, 2 = no MFMA / fragment reads, 4 = no weight loads, 8 = no partial-tile stores, 16 = no finish launch (garbage results)
+#endif
         PGV_TRY(kK8[w8][c.ct == 1 ? 0 : (c.ct == 2 ? 1 : 2)][c.nwb == 10](dtype, a, grid, norm->k8_part, s));
     } else {
         const GemvShape* shape = nullptr;
